@@ -1,0 +1,279 @@
+"""dsm_amd — Python binding of libdsm_mi355x.so (the C ABI in include/dsm.h).
+
+This is plumbing for tests / bench / smoke: ctypes mirrors of the config structs and thin
+wrappers that hand numpy (host) or torch (device) buffers to the C entry points.  The compute
+lives in the HIP library; there is NO Python or CPU fallback — if the library or the GPU is
+missing, calls raise.
+
+The directory name carries a hyphen (it mirrors the upstream repo name), so import it through
+the `dsm_amd` shim at the repo root.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdsm_mi355x.so")
+
+FRAME_SIZE = 1920
+MAX_RATIOS = 8
+MAX_EXTRA_HEADS = 8
+
+
+class TransformerConfig(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "d_model", "num_heads", "num_layers", "dim_feedforward", "context", "max_period",
+        "gating", "norm", "positional_embedding", "layer_scale", "conv_layout")]
+
+
+class MimiConfig(C.Structure):
+    _fields_ = [
+        ("channels", C.c_int), ("dimension", C.c_int), ("n_filters", C.c_int),
+        ("n_residual_layers", C.c_int), ("n_ratios", C.c_int), ("ratios", C.c_int * MAX_RATIOS),
+        ("kernel_size", C.c_int), ("residual_kernel_size", C.c_int), ("last_kernel_size", C.c_int),
+        ("dilation_base", C.c_int), ("compress", C.c_int), ("transformer", TransformerConfig),
+        ("quantizer_n_q", C.c_int), ("quantizer_bins", C.c_int), ("quantizer_dim", C.c_int),
+        ("downsample_stride", C.c_int)]
+
+
+class AsrConfig(C.Structure):
+    _fields_ = [
+        ("lm", TransformerConfig), ("text_in_vocab_size", C.c_int), ("text_out_vocab_size", C.c_int),
+        ("audio_vocab_size", C.c_int), ("audio_codebooks", C.c_int), ("extra_heads_num", C.c_int),
+        ("extra_heads_dim", C.c_int), ("asr_delay_in_tokens", C.c_int), ("temperature", C.c_float),
+        ("mimi", MimiConfig), ("kv_bf16", C.c_int)]
+
+    def copy(self):
+        out = AsrConfig()
+        C.memmove(C.byref(out), C.byref(self), C.sizeof(AsrConfig))
+        return out
+
+
+class AsrMsg(C.Structure):
+    _fields_ = [("kind", C.c_int), ("batch_idx", C.c_int), ("step_idx", C.c_int), ("time", C.c_double),
+                ("tokens_offset", C.c_int), ("n_tokens", C.c_int), ("prs", C.c_float * MAX_EXTRA_HEADS)]
+
+
+class Metrics(C.Structure):
+    _fields_ = [("last_encode_us", C.c_double), ("last_lm_us", C.c_double),
+                ("algorithmic_bytes_encode", C.c_double), ("algorithmic_bytes_lm", C.c_double),
+                ("steps_encode", C.c_uint64), ("steps_lm", C.c_uint64)]
+
+
+MSG_STEP, MSG_WORD, MSG_END_WORD = 0, 1, 2
+
+# Every symbol include/dsm.h declares (the "not gpu" tests check the library exports all of them).
+ABI_SYMBOLS = [
+    "dsm_mimi_config_v0_1", "dsm_asr_config_stt_1b_en_fr", "dsm_asr_config_stt_2_6b_en",
+    "dsm_asr_create", "dsm_destroy", "dsm_last_error", "dsm_mimi_encode_step", "dsm_asr_step_tokens",
+    "dsm_asr_step_pcm", "dsm_asr_poll_msgs", "dsm_asr_reset_slot", "dsm_mimi_reset_slot", "dsm_sync",
+    "dsm_get_metrics", "dsm_batch_size", "dsm_n_q", "dsm_mimi_encode_step_dev", "dsm_asr_step_tokens_dev",
+    "dsm_streams_join", "dsm_debug_read",
+]
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen the HIP library (no GPU needed for this) and declare signatures."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(
+            f"{p} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`. "
+            "There is no CPU fallback for the MI355X engine.")
+    lib = C.CDLL(p)
+    vp, ip, u8p, u32p, fp = C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p
+    lib.dsm_mimi_config_v0_1.argtypes = [C.POINTER(MimiConfig), C.c_int]
+    lib.dsm_asr_config_stt_1b_en_fr.argtypes = [C.POINTER(AsrConfig)]
+    lib.dsm_asr_config_stt_2_6b_en.argtypes = [C.POINTER(AsrConfig)]
+    lib.dsm_asr_create.argtypes = [C.POINTER(AsrConfig), C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.POINTER(vp)]
+    lib.dsm_asr_create.restype = C.c_int
+    lib.dsm_destroy.argtypes = [vp]
+    lib.dsm_destroy.restype = None
+    lib.dsm_last_error.argtypes = [vp]
+    lib.dsm_last_error.restype = C.c_char_p
+    lib.dsm_mimi_encode_step.argtypes = [vp, fp, u8p, u32p, C.POINTER(C.c_int)]
+    lib.dsm_asr_step_tokens.argtypes = [vp, u32p, u8p, u32p, fp]
+    lib.dsm_asr_step_pcm.argtypes = [vp, fp, u8p, u32p, u32p, fp]
+    lib.dsm_asr_poll_msgs.argtypes = [vp, C.POINTER(AsrMsg), C.c_int, u32p, C.c_int]
+    lib.dsm_asr_reset_slot.argtypes = [vp, C.c_int]
+    lib.dsm_mimi_reset_slot.argtypes = [vp, C.c_int]
+    lib.dsm_sync.argtypes = [vp]
+    lib.dsm_get_metrics.argtypes = [vp, C.POINTER(Metrics)]
+    lib.dsm_batch_size.argtypes = [vp]
+    lib.dsm_n_q.argtypes = [vp]
+    lib.dsm_mimi_encode_step_dev.argtypes = [vp, vp, vp, vp]
+    lib.dsm_asr_step_tokens_dev.argtypes = [vp, vp, vp, vp, vp]
+    lib.dsm_streams_join.argtypes = [vp]
+    lib.dsm_debug_read.argtypes = [vp, C.c_char_p, fp, C.c_size_t]
+    for name in ("dsm_mimi_encode_step", "dsm_asr_step_tokens", "dsm_asr_step_pcm", "dsm_asr_poll_msgs",
+                 "dsm_asr_reset_slot", "dsm_mimi_reset_slot", "dsm_sync", "dsm_get_metrics", "dsm_batch_size",
+                 "dsm_n_q", "dsm_mimi_encode_step_dev", "dsm_asr_step_tokens_dev", "dsm_streams_join",
+                 "dsm_debug_read"):
+        getattr(lib, name).restype = C.c_int
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def config_stt_1b_en_fr():
+    cfg = AsrConfig()
+    load_library().dsm_asr_config_stt_1b_en_fr(C.byref(cfg))
+    return cfg
+
+
+def config_stt_2_6b_en():
+    cfg = AsrConfig()
+    load_library().dsm_asr_config_stt_2_6b_en(C.byref(cfg))
+    return cfg
+
+
+def config_tiny(kv_bf16=1):
+    """A small configuration with every structural feature of stt-1b-en_fr (same ratios, T shapes,
+    ring-cache wrap within a few steps) that the CPU oracle steps in milliseconds."""
+    cfg = AsrConfig()
+    t = cfg.lm
+    t.d_model, t.num_heads, t.num_layers, t.dim_feedforward = 128, 4, 2, 512
+    t.context, t.max_period, t.gating, t.norm = 12, 100000, 1, 1
+    t.positional_embedding, t.layer_scale, t.conv_layout = 1, 0, 0
+    cfg.text_in_vocab_size, cfg.text_out_vocab_size = 65, 64
+    cfg.audio_vocab_size, cfg.audio_codebooks = 33, 4
+    cfg.extra_heads_num, cfg.extra_heads_dim = 2, 6
+    cfg.asr_delay_in_tokens, cfg.temperature, cfg.kv_bf16 = 2, 0.0, kv_bf16
+    m = cfg.mimi
+    m.channels, m.dimension, m.n_filters, m.n_residual_layers = 1, 64, 4, 1
+    m.n_ratios = 4
+    for i, r in enumerate((8, 6, 5, 4)):
+        m.ratios[i] = r
+    m.kernel_size, m.residual_kernel_size, m.last_kernel_size = 7, 3, 3
+    m.dilation_base, m.compress = 2, 2
+    mt = m.transformer
+    mt.d_model, mt.num_heads, mt.num_layers, mt.dim_feedforward = 64, 2, 2, 128
+    mt.context, mt.max_period, mt.gating, mt.norm = 10, 10000, 0, 0
+    mt.positional_embedding, mt.layer_scale, mt.conv_layout = 1, 1, 1
+    m.quantizer_n_q, m.quantizer_bins, m.quantizer_dim, m.downsample_stride = 4, 32, 16, 2
+    return cfg
+
+
+def _ptr(a):
+    """Host pointer of a C-contiguous numpy array (or None)."""
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class DsmError(RuntimeError):
+    pass
+
+
+class AsrEngine:
+    """Mirror of the reference's (Mimi::batched, LmModel::batched, asr::State) triple behind the C ABI.
+
+    Method names follow the reference: encode_step (core/mimi.rs:195), step_tokens (core/asr.rs:147),
+    step_pcm (core/asr.rs:115), reset_batch_idx (core/asr.rs:257)."""
+
+    def __init__(self, cfg, batch_size, lm_path, mimi_path, device_id=0):
+        self.lib = load_library()
+        self.cfg = cfg
+        self.B = batch_size
+        h = C.c_void_p()
+        rc = self.lib.dsm_asr_create(C.byref(cfg), device_id, batch_size, lm_path.encode(), mimi_path.encode(),
+                                     C.byref(h))
+        if rc != 0:
+            msg = self.lib.dsm_last_error(None)
+            raise DsmError(f"dsm_asr_create failed ({rc}): {msg.decode() if msg else '?'}")
+        self.h = h
+        self.n_q = self.lib.dsm_n_q(h)
+
+    def _check(self, rc):
+        if rc < 0:
+            msg = self.lib.dsm_last_error(self.h)
+            raise DsmError(f"dsm error {rc}: {msg.decode() if msg else '?'}")
+        return rc
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.dsm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def encode_step(self, pcm, mask):
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32).reshape(self.B, FRAME_SIZE)
+        mask = np.ascontiguousarray(mask, dtype=np.uint8).reshape(self.B)
+        codes = np.zeros((self.B, self.n_q), dtype=np.uint32)
+        produced = C.c_int(0)
+        self._check(self.lib.dsm_mimi_encode_step(self.h, _ptr(pcm), _ptr(mask), _ptr(codes), C.byref(produced)))
+        return codes if produced.value else None
+
+    def step_tokens(self, codes, mask):
+        codes = np.ascontiguousarray(codes, dtype=np.uint32).reshape(self.B, self.n_q)
+        mask = np.ascontiguousarray(mask, dtype=np.uint8).reshape(self.B)
+        text = np.zeros(self.B, dtype=np.uint32)
+        nh = self.cfg.extra_heads_num
+        prs = np.zeros((max(nh, 1), self.B), dtype=np.float32)
+        self._check(self.lib.dsm_asr_step_tokens(self.h, _ptr(codes), _ptr(mask), _ptr(text), _ptr(prs) if nh else None))
+        return text, prs[:nh]
+
+    def step_pcm(self, pcm, mask):
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32).reshape(self.B, FRAME_SIZE)
+        mask = np.ascontiguousarray(mask, dtype=np.uint8).reshape(self.B)
+        codes = np.zeros((self.B, self.n_q), dtype=np.uint32)
+        text = np.zeros(self.B, dtype=np.uint32)
+        nh = self.cfg.extra_heads_num
+        prs = np.zeros((max(nh, 1), self.B), dtype=np.float32)
+        self._check(self.lib.dsm_asr_step_pcm(self.h, _ptr(pcm), _ptr(mask), _ptr(codes), _ptr(text),
+                                              _ptr(prs) if nh else None))
+        return codes, text, prs[:nh]
+
+    def poll_msgs(self, cap=4096):
+        msgs = (AsrMsg * cap)()
+        toks = np.zeros(cap * 8, dtype=np.uint32)
+        n = self._check(self.lib.dsm_asr_poll_msgs(self.h, msgs, cap, _ptr(toks), toks.size))
+        out = []
+        for i in range(n):
+            m = msgs[i]
+            if m.kind == MSG_WORD:
+                out.append(("Word", m.batch_idx, m.time, toks[m.tokens_offset:m.tokens_offset + m.n_tokens].tolist()))
+            elif m.kind == MSG_END_WORD:
+                out.append(("EndWord", m.batch_idx, m.time))
+            else:
+                out.append(("Step", m.step_idx))
+        return out
+
+    def reset_batch_idx(self, slot):
+        self._check(self.lib.dsm_asr_reset_slot(self.h, slot))
+
+    def mimi_reset_batch_idx(self, slot):
+        self._check(self.lib.dsm_mimi_reset_slot(self.h, slot))
+
+    def sync(self):
+        self._check(self.lib.dsm_sync(self.h))
+
+    def metrics(self):
+        m = Metrics()
+        self._check(self.lib.dsm_get_metrics(self.h, C.byref(m)))
+        return m
+
+    def debug_read(self, name, n):
+        out = np.zeros(n, dtype=np.float32)
+        got = self._check(self.lib.dsm_debug_read(self.h, name.encode(), _ptr(out), n))
+        return out[:got]
+
+    # device-pointer variants (ints from torch.Tensor.data_ptr())
+    def encode_step_dev(self, d_pcm, d_mask, d_codes):
+        self._check(self.lib.dsm_mimi_encode_step_dev(self.h, d_pcm, d_mask, d_codes))
+
+    def step_tokens_dev(self, d_codes, d_mask, d_text, d_prs):
+        self._check(self.lib.dsm_asr_step_tokens_dev(self.h, d_codes, d_mask, d_text, d_prs))
+
+    def streams_join(self):
+        self._check(self.lib.dsm_streams_join(self.h))

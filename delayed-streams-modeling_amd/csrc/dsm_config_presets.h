@@ -1,0 +1,81 @@
+/*
+ * dsm_config_presets.h — the shipped configurations as C structs.
+ * Sources: core/mimi.rs:32-93 (Mimi v0_1), configs/stt/config-stt-en_fr-hf.toml:18-56,
+ * configs/stt/config-stt-en-hf.toml:18-49 (reference tree /root/reference).
+ */
+#ifndef DSM_CONFIG_PRESETS_H
+#define DSM_CONFIG_PRESETS_H
+#include <string.h>
+#include "../../include/dsm.h"
+
+static inline void dsm_preset_mimi_v0_1(dsm_mimi_config* m, int num_codebooks) {
+  memset(m, 0, sizeof *m);
+  m->channels = 1;
+  m->dimension = 512;
+  m->n_filters = 64;
+  m->n_residual_layers = 1;
+  m->n_ratios = 4;
+  m->ratios[0] = 8; m->ratios[1] = 6; m->ratios[2] = 5; m->ratios[3] = 4;
+  m->kernel_size = 7;
+  m->residual_kernel_size = 3;
+  m->last_kernel_size = 3;
+  m->dilation_base = 2;
+  m->compress = 2;
+  m->transformer.d_model = 512;
+  m->transformer.num_heads = 8;
+  m->transformer.num_layers = 8;
+  m->transformer.dim_feedforward = 2048;
+  m->transformer.context = 250;
+  m->transformer.max_period = 10000;
+  m->transformer.gating = 0;
+  m->transformer.norm = 0;
+  m->transformer.positional_embedding = 1;
+  m->transformer.layer_scale = 1;
+  m->transformer.conv_layout = 1;
+  m->quantizer_n_q = num_codebooks > 0 ? num_codebooks : 16;
+  m->quantizer_bins = 2048;
+  m->quantizer_dim = 256;
+  m->downsample_stride = 2; /* 24000 / (8*6*5*4) = 25 Hz encoder rate over 12.5 Hz frame rate */
+}
+
+static inline void dsm_preset_stt_common(dsm_asr_config* c) {
+  memset(c, 0, sizeof *c);
+  c->lm.d_model = 2048;
+  c->lm.dim_feedforward = 8192;
+  c->lm.max_period = 100000;
+  c->lm.gating = 1;
+  c->lm.norm = 1;
+  c->lm.positional_embedding = 1;
+  c->lm.layer_scale = 0;
+  c->lm.conv_layout = 0;
+  c->audio_vocab_size = 2049;
+  c->audio_codebooks = 32;
+  c->temperature = 0.0f;
+  c->kv_bf16 = 1;
+  dsm_preset_mimi_v0_1(&c->mimi, 32); /* srv/batched_asr.rs:754-757: Config::v0_1(Some(audio_codebooks)) */
+}
+
+static inline void dsm_preset_stt_1b_en_fr(dsm_asr_config* c) {
+  dsm_preset_stt_common(c);
+  c->lm.num_heads = 16;
+  c->lm.num_layers = 16;
+  c->lm.context = 750;
+  c->text_in_vocab_size = 8001;
+  c->text_out_vocab_size = 8000;
+  c->extra_heads_num = 4;
+  c->extra_heads_dim = 6;
+  c->asr_delay_in_tokens = 6;
+}
+
+static inline void dsm_preset_stt_2_6b_en(dsm_asr_config* c) {
+  dsm_preset_stt_common(c);
+  c->lm.num_heads = 32;
+  c->lm.num_layers = 48;
+  c->lm.context = 375;
+  c->text_in_vocab_size = 4001;
+  c->text_out_vocab_size = 4000;
+  c->extra_heads_num = 0;
+  c->extra_heads_dim = 0;
+  c->asr_delay_in_tokens = 32;
+}
+#endif

@@ -1,0 +1,203 @@
+/*
+ * dsm.h — C ABI of libdsm_mi355x.so: the MI355X-native replacement for the per-80 ms-frame
+ * batched step of moshi-server's BatchedAsr worker (reference: /root/reference,
+ * server/rust/moshi/moshi-server/src/batched_asr.rs calling into moshi-core).
+ *
+ * The reference boundary is a Rust API (no FFI exists upstream).  Each entry point below
+ * names the Rust call it replaces; INTEGRATION.md shows the `extern "C"` shim a maintainer
+ * adds on the Rust side.  Plain pointers and sizes only — no torch / candle types.
+ *
+ * Conventions
+ *   - return 0 on success, <0 on error (DSM_ERR_*); dsm_last_error() gives the message.
+ *     The reference bubbles candle::Error up and kills the loop thread
+ *     (srv/utils.rs:376-384); here the caller decides.
+ *   - the caller owns every host buffer; the engine owns all device memory.
+ *   - B = batch_size = number of stream slots; one frame = 1920 f32 samples @ 24 kHz = 80 ms
+ *     (srv/batched_asr.rs:26).
+ *   - mask[b] != 0  <=>  slot b is active this step (core/streaming.rs:20-68 StreamMask).
+ *   - threading: like the reference, dsm_mimi_encode_step may run on an "encoder" thread
+ *     while dsm_asr_step_tokens / dsm_asr_reset_slot run on a "model" thread
+ *     (srv/batched_asr.rs:314-522); the two sides use separate HIP streams and state.
+ */
+#ifndef DSM_H
+#define DSM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSM_FRAME_SIZE 1920 /* srv/batched_asr.rs:26 FRAME_SIZE */
+#define DSM_MAX_RATIOS 8
+#define DSM_MAX_EXTRA_HEADS 8
+
+enum {
+  DSM_OK = 0,
+  DSM_ERR_INVALID = -1,  /* bad argument / config (candle::bail! paths) */
+  DSM_ERR_IO = -2,       /* weight file missing / malformed / tensor key or shape mismatch */
+  DSM_ERR_DEVICE = -3,   /* HIP error */
+  DSM_ERR_STATE = -4     /* call sequence the reference would reject */
+};
+
+/* transformer::Config — core/transformer.rs:21-53 (fields the batched path reads). */
+typedef struct dsm_transformer_config {
+  int d_model;
+  int num_heads;
+  int num_layers;
+  int dim_feedforward;
+  int context;          /* ring KV-cache length (core/kv_cache.rs:88-93) */
+  int max_period;       /* RoPE theta (core/batched_transformer.rs:385-389) */
+  int gating;           /* 0 = None (linear1/gelu_erf/linear2), 1 = silu gating (core/batched_transformer.rs:142-179) */
+  int norm;             /* 0 = LayerNorm eps 1e-5, 1 = RmsNorm eps 1e-8 (core/batched_transformer.rs:236-252) */
+  int positional_embedding; /* 0 = None, 1 = Rope */
+  int layer_scale;      /* 0 = absent, 1 = layer_scale_{1,2}.scale present (core/batched_transformer.rs:291-304) */
+  int conv_layout;      /* 1 = caller layout is [B,C,T] (Mimi), 0 = [B,T,C] (core/batched_transformer.rs:584-602) */
+} dsm_transformer_config;
+
+/* seanet::Config + mimi::Config — core/seanet.rs:12-31, core/mimi.rs:17-93 (v0_1 values in comments). */
+typedef struct dsm_mimi_config {
+  int channels;              /* 1 */
+  int dimension;             /* 512 */
+  int n_filters;             /* 64 */
+  int n_residual_layers;     /* 1 */
+  int n_ratios;              /* 4 */
+  int ratios[DSM_MAX_RATIOS];/* {8,6,5,4} — the ENCODER applies them reversed (core/seanet.rs:194) */
+  int kernel_size;           /* 7 */
+  int residual_kernel_size;  /* 3 */
+  int last_kernel_size;      /* 3 */
+  int dilation_base;         /* 2 */
+  int compress;              /* 2 */
+  dsm_transformer_config transformer; /* d 512, 8 heads, 8 layers, ffn 2048, ctx 250, theta 10000, LayerNorm, layer_scale, conv_layout */
+  int quantizer_n_q;         /* 32 for STT (srv/batched_asr.rs:754-757), 16 default */
+  int quantizer_bins;        /* 2048 */
+  int quantizer_dim;         /* 256 */
+  int downsample_stride;     /* encoder_frame_rate / frame_rate = 25 / 12.5 = 2 (core/mimi.rs:141-144) */
+} dsm_mimi_config;
+
+/* ModuleConfig::BatchedAsr + lm::Config — srv/main.rs:110-128,179-184, core/lm.rs:36-46. */
+typedef struct dsm_asr_config {
+  dsm_transformer_config lm;
+  int text_in_vocab_size;
+  int text_out_vocab_size;
+  int audio_vocab_size;
+  int audio_codebooks;
+  int extra_heads_num;   /* [modules.asr.model.extra_heads] num_heads (0 if absent) */
+  int extra_heads_dim;
+  int asr_delay_in_tokens;
+  float temperature;     /* only 0 (argmax) is on the accelerated path (core/asr.rs:208-216) */
+  dsm_mimi_config mimi;
+  /* engine numerics: 1 = K/V ring cache stored as bf16 (GPU target, BASELINE.md roofline),
+   * 0 = f32 cache (the Candle CPU path's dtype, srv/utils.rs:386-395). */
+  int kv_bf16;
+} dsm_asr_config;
+
+/* Presets matching configs/stt/config-stt-en_fr-hf.toml and config-stt-en-hf.toml. */
+void dsm_mimi_config_v0_1(dsm_mimi_config* out, int num_codebooks);
+void dsm_asr_config_stt_1b_en_fr(dsm_asr_config* out);
+void dsm_asr_config_stt_2_6b_en(dsm_asr_config* out);
+
+typedef struct dsm_engine dsm_engine; /* opaque: one per (device, BatchedAsr module) */
+
+/* AsrMsg — core/asr.rs:9-13.  Word tokens are returned through a side buffer. */
+enum { DSM_MSG_STEP = 0, DSM_MSG_WORD = 1, DSM_MSG_END_WORD = 2 };
+typedef struct dsm_asr_msg {
+  int kind;
+  int batch_idx;       /* Word / EndWord */
+  int step_idx;        /* Step: model_step_idx after the step */
+  double time;         /* Word: start_time, EndWord: stop_time (seconds) */
+  int tokens_offset;   /* Word: tokens live in tokens_out[offset .. offset+n_tokens) */
+  int n_tokens;
+  float prs[DSM_MAX_EXTRA_HEADS]; /* unused here; Step probabilities come from vad_prs_out */
+} dsm_asr_msg;
+
+typedef struct dsm_metrics {
+  double last_encode_us;     /* device time of the last dsm_mimi_encode_step (HIP events) */
+  double last_lm_us;         /* device time of the last dsm_asr_step_tokens */
+  double algorithmic_bytes_encode; /* BASELINE.md bytes_step() terms, for roofline.achieved */
+  double algorithmic_bytes_lm;
+  uint64_t steps_encode;
+  uint64_t steps_lm;
+} dsm_metrics;
+
+/*
+ * Create.  Replaces LmModel::batched + Mimi::batched + asr::State::new
+ * (srv/batched_asr.rs:738-758, 272-278; core/lm.rs:816; core/mimi.rs:113; core/asr.rs:65).
+ * Reads the same safetensors keys as the reference; LM tensors must be
+ * BF16 or F32 (stored as bf16 on device), Mimi tensors F32/BF16 (stored as f32,
+ * core/mimi.rs:250-255).  Fails with DSM_ERR_DEVICE if no gfx950 device is usable — there
+ * is no CPU fallback in this library.
+ */
+int dsm_asr_create(const dsm_asr_config* cfg, int device_id, int batch_size,
+                   const char* lm_safetensors, const char* mimi_safetensors, dsm_engine** out);
+void dsm_destroy(dsm_engine*);
+const char* dsm_last_error(const dsm_engine*); /* NULL engine -> last create error */
+
+/*
+ * Mimi::encode_step(&StreamTensor, &StreamMask) — core/mimi.rs:195-206, called at
+ * srv/batched_asr.rs:362 (encoder thread).  pcm: host [B*1920] f32; mask: host [B] u8;
+ * codes_out: host [B*n_q] u32 (slot-major, [B, n_q, 1] like the reference) or NULL to keep
+ * the codes on the device for a following dsm_asr_step_tokens(codes == NULL).
+ * *produced = number of frames emitted (always 1 for 1920-sample frames).
+ * Codes of inactive slots are unspecified (the reference computes garbage for them and
+ * ignores it: core/asr.rs:177-183).
+ */
+int dsm_mimi_encode_step(dsm_engine*, const float* pcm, const uint8_t* mask, uint32_t* codes_out,
+                         int* produced);
+
+/*
+ * asr::State::step_tokens(&Tensor[B,n_q,1], None, &StreamMask, f) — core/asr.rs:147-255,
+ * called at srv/batched_asr.rs:476 (model thread).  codes: host [B*n_q] u32 or NULL (use the
+ * device-resident output of the last encode step).  text_tokens_out: host [B] u32 (argmax
+ * per slot, valid for active slots).  vad_prs_out: host [extra_heads_num*B] f32 (class-0
+ * probability of every extra head, layout [head][slot], core/asr.rs:195-203) or NULL.
+ * Word/EndWord/Step messages produced by this step are queued for dsm_asr_poll_msgs.
+ */
+int dsm_asr_step_tokens(dsm_engine*, const uint32_t* codes, const uint8_t* mask,
+                        uint32_t* text_tokens_out, float* vad_prs_out);
+
+/* asr::State::step_pcm — core/asr.rs:115-131 (warmup path, srv/batched_asr.rs:236):
+ * encode_step on the MODEL side's own Mimi state followed by step_tokens. */
+int dsm_asr_step_pcm(dsm_engine*, const float* pcm, const uint8_t* mask, uint32_t* codes_out,
+                     uint32_t* text_tokens_out, float* vad_prs_out);
+
+/* Drain the Vec<AsrMsg> the last step returned.  Returns the number of messages written
+ * (<= cap); word tokens are copied to tokens_out (tokens_cap entries). */
+int dsm_asr_poll_msgs(dsm_engine*, dsm_asr_msg* msgs, int cap, uint32_t* tokens_out, int tokens_cap);
+
+/* asr::State::reset_batch_idx(slot) — core/asr.rs:257-266, srv/batched_asr.rs:467-471.
+ * Resets the LM slot (KV index/position, item state) and the MODEL side's Mimi slot.
+ * The reference never resets the ENCODER thread's Mimi clone;
+ * dsm_mimi_reset_slot exposes that missing reset explicitly instead of hiding a
+ * behaviour change inside dsm_asr_reset_slot. */
+int dsm_asr_reset_slot(dsm_engine*, int slot);
+int dsm_mimi_reset_slot(dsm_engine*, int slot);
+
+/* Device::synchronize — srv/batched_asr.rs:238. */
+int dsm_sync(dsm_engine*);
+
+int dsm_get_metrics(dsm_engine*, dsm_metrics* out);
+int dsm_batch_size(const dsm_engine*);
+int dsm_n_q(const dsm_engine*); /* mimi.config().quantizer_n_q — srv/batched_asr.rs:379 */
+
+/*
+ * Device-resident variants for callers that already hold HBM buffers (bench.py's timed
+ * region; a Rust caller with hipMalloc'd staging).  Pointers are DEVICE pointers, nothing
+ * is synchronised; work is enqueued on the engine's encoder / model stream.
+ */
+int dsm_mimi_encode_step_dev(dsm_engine*, const float* d_pcm, const uint8_t* d_mask, uint32_t* d_codes_out);
+int dsm_asr_step_tokens_dev(dsm_engine*, const uint32_t* d_codes, const uint8_t* d_mask,
+                            uint32_t* d_text_tokens_out, float* d_vad_prs_out);
+/* Make the model stream wait for everything enqueued so far on the encoder stream. */
+int dsm_streams_join(dsm_engine*);
+
+/* Debug taps for the parity tests: copy a named intermediate of the last step to the host.
+ * Names: "lm.hidden" [B,d], "lm.logits" [B,V], "mimi.seanet_out" [B,T,dim], "mimi.latent" [B,dim] ...
+ * Returns the number of floats written, or <0. */
+int dsm_debug_read(dsm_engine*, const char* name, float* out, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSM_H */

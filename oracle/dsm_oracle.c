@@ -1,0 +1,1511 @@
+/*
+ * dsm_oracle.c — CPU oracle (TEST INFRASTRUCTURE, see dsm_oracle.h).
+ *
+ * Restates, in order, the reference files of SURVEY.md §8(c):
+ *   core/conv.rs -> core/seanet.rs -> core/streaming.rs -> core/kv_cache.rs ->
+ *   core/transformer.rs:366-403 (Rope) -> core/batched_transformer.rs -> core/quantization.rs ->
+ *   core/mimi.rs -> core/lm.rs:796-1008 -> core/asr.rs
+ * ("core/" = /root/reference/server/rust/moshi/moshi-core/src/).
+ *
+ * Tensors that the reference keeps as [B,C,T] (conv layout) are kept channels-last [B,T,C]
+ * here; that is a pure relabelling (every op is restated on the relabelled axes).
+ * Floating point follows the numerics contract of csrc/dsm_numerics.h: f32 everywhere
+ * (the Candle CPU path's dtype: srv/utils.rs:386-395, srv/batched_asr.rs:746-753), with the
+ * canonical summation orders defined there.  Candle's own summation order (gemm crate) is
+ * implementation-defined and unavailable offline, so float-level parity with Candle is
+ * unpinned by construction; integer outputs are compared bit-exactly against THIS file.
+ */
+#include "dsm_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../delayed-streams-modeling_amd/csrc/dsm_numerics.h"
+#include "../delayed-streams-modeling_amd/csrc/dsm_safetensors.h"
+
+#define ORC_NEG_INF (-INFINITY)
+#define MAXI(a, b) ((a) > (b) ? (a) : (b))
+#define MINI(a, b) ((a) < (b) ? (a) : (b))
+
+static void* xmalloc(size_t n) {
+  void* p = malloc(n ? n : 1);
+  if (!p) {
+    fprintf(stderr, "oracle: out of memory (%zu bytes)\n", n);
+    abort();
+  }
+  return p;
+}
+static void* xcalloc(size_t n, size_t s) {
+  void* p = calloc(n ? n : 1, s);
+  if (!p) {
+    fprintf(stderr, "oracle: out of memory\n");
+    abort();
+  }
+  return p;
+}
+
+/* ======================================================================================
+ * Canonical dot / linear  (every Tensor::matmul / candle_nn::Linear / Conv1d call site:
+ * core/batched_transformer.rs:77,108,112,119,171,175; core/lm.rs:1003; core/quantization.rs:128;
+ * core/conv.rs:96)
+ * ====================================================================================== */
+
+/* visiting order of the K elements: chunks of DSM_KC, 32-blocks, s outer, q inner */
+static int* dot_order(int K) {
+  int* ord = (int*)xmalloc(sizeof(int) * (size_t)K);
+  int n = 0;
+  for (int blk = 0; blk < K; blk += 32)
+    for (int s = 0; s < 8; ++s)
+      for (int q = 0; q < 4; ++q) {
+        int k = blk + 8 * q + s;
+        if (k < K) ord[n++] = k;
+      }
+  return ord;
+}
+
+float orc_dot(const float* x, const float* w, int K) {
+  float total = 0.0f;
+  for (int c0 = 0; c0 < K; c0 += DSM_KC) {
+    int c1 = MINI(c0 + DSM_KC, K);
+    float acc = 0.0f;
+    for (int blk = c0; blk < c1; blk += 32)
+      for (int s = 0; s < 8; ++s)
+        for (int q = 0; q < 4; ++q) {
+          int k = blk + 8 * q + s;
+          if (k < c1) acc = DSM_FMAF(x[k], w[k], acc);
+        }
+    total = (c0 == 0) ? acc : total + acc;
+  }
+  return total;
+}
+
+/* y[m*ldy + n] = orc_dot(x + m*ldx, W + n*ldw, K) + bias[n]   (bias may be NULL)
+ * Same arithmetic as orc_dot, arranged so that 64 rows advance together (vectorises). */
+void orc_linear(float* y, int ldy, const float* x, int ldx, const float* W, int ldw, const float* bias, int M,
+                int N, int K) {
+  int* ord = dot_order(K);
+  enum { MB = 64 };
+  float* xT = (float*)xmalloc(sizeof(float) * (size_t)K * MB);
+  for (int m0 = 0; m0 < M; m0 += MB) {
+    int mb = MINI(MB, M - m0);
+    for (int kk = 0; kk < K; ++kk) {
+      int k = ord[kk];
+      for (int mi = 0; mi < MB; ++mi) xT[(size_t)kk * MB + mi] = mi < mb ? x[(size_t)(m0 + mi) * ldx + k] : 0.0f;
+    }
+#pragma omp parallel for schedule(static)
+    for (int n = 0; n < N; ++n) {
+      const float* wr = W + (size_t)n * ldw;
+      float total[MB], acc[MB];
+      /* position kk in visiting order <-> chunk: a chunk holds the k in [c0, c1), and the
+       * visiting order never leaves a chunk before it is finished. */
+      int kk = 0;
+      for (int c0 = 0; c0 < K; c0 += DSM_KC) {
+        int c1 = MINI(c0 + DSM_KC, K);
+        for (int mi = 0; mi < MB; ++mi) acc[mi] = 0.0f;
+        for (int cnt = c1 - c0; cnt > 0; --cnt, ++kk) {
+          float wv = wr[ord[kk]];
+          const float* xr = xT + (size_t)kk * MB;
+          for (int mi = 0; mi < MB; ++mi) acc[mi] = DSM_FMAF(xr[mi], wv, acc[mi]);
+        }
+        if (c0 == 0)
+          for (int mi = 0; mi < MB; ++mi) total[mi] = acc[mi];
+        else
+          for (int mi = 0; mi < MB; ++mi) total[mi] = total[mi] + acc[mi];
+      }
+      float bv = bias ? bias[n] : 0.0f;
+      for (int mi = 0; mi < mb; ++mi) y[(size_t)(m0 + mi) * ldy + n] = bias ? total[mi] + bv : total[mi];
+    }
+  }
+  free(xT);
+  free(ord);
+}
+
+/* ======================================================================================
+ * Row reductions: one "wave" of 64 lanes per row, lane l owns elements 256*it + 4*l + j.
+ * ====================================================================================== */
+static float row_sum_canon(const float* x, int d, int squares) {
+  float part[64];
+  for (int l = 0; l < 64; ++l) {
+    float acc = 0.0f;
+    for (int it = 0; it * 256 < d; ++it)
+      for (int j = 0; j < 4; ++j) {
+        int i = it * 256 + 4 * l + j;
+        if (i < d) acc = squares ? DSM_FMAF(x[i], x[i], acc) : acc + x[i];
+      }
+    part[l] = acc;
+  }
+  dsm_butterfly_sum(part, 64);
+  return part[0];
+}
+
+/* candle_nn::ops::rms_norm — core/batched_transformer.rs:194-198 (eps 1e-8, :247) */
+void orc_rmsnorm(float* y, const float* x, const float* alpha, int rows, int d, float eps) {
+  for (int r = 0; r < rows; ++r) {
+    const float* xr = x + (size_t)r * d;
+    float ss = row_sum_canon(xr, d, 1);
+    float m = sqrtf(ss / (float)d + eps);
+    for (int i = 0; i < d; ++i) y[(size_t)r * d + i] = (xr[i] / m) * alpha[i];
+  }
+}
+
+/* candle_nn::LayerNorm — core/batched_transformer.rs:200-222 (eps 1e-5, :243) */
+void orc_layernorm(float* y, const float* x, const float* w, const float* b, int rows, int d, float eps) {
+  for (int r = 0; r < rows; ++r) {
+    const float* xr = x + (size_t)r * d;
+    float s = row_sum_canon(xr, d, 0);
+    float s2 = row_sum_canon(xr, d, 1);
+    float mean = s / (float)d;
+    float var = s2 / (float)d - mean * mean;
+    float inv = 1.0f / sqrtf(var + eps);
+    for (int i = 0; i < d; ++i) y[(size_t)r * d + i] = ((xr[i] - mean) * inv) * w[i] + b[i];
+  }
+}
+
+/* ======================================================================================
+ * Rope — core/transformer.rs:366-403.  inv_freq_i = 1 / theta^(2i/hd); angle = pos * inv_freq
+ * in f32; interleaved pairs (rope_i).
+ * ====================================================================================== */
+void orc_rope_table(int hd, int max_period, float* inv_freq) {
+  for (int i = 0; i < hd / 2; ++i)
+    inv_freq[i] = (float)(1.0 / pow((double)max_period, (double)(2 * i) / (double)hd));
+}
+
+void orc_rope_apply(float* x, int hd, const float* inv_freq, uint32_t pos) {
+  for (int i = 0; i < hd / 2; ++i) {
+    float ang = (float)pos * inv_freq[i];
+    float s, c;
+    dsm_sincosf(ang, &s, &c);
+    float x0 = x[2 * i], x1 = x[2 * i + 1];
+    float a = x0 * c, b = x1 * s, e = x0 * s, f = x1 * c;
+    x[2 * i] = a - b;
+    x[2 * i + 1] = e + f;
+  }
+}
+
+/* ======================================================================================
+ * Attention for one (slot, head) — core/batched_transformer.rs:107-113:
+ *   softmax(q.K^T * hd^-0.5 + mask) . V  over the whole ring buffer.
+ * Canonical order: 4 waves, LPK = hd/8 lanes per key, G = 64/LPK keys per
+ * wave-iteration, key j -> wave (j/G)%4, lane group j%G.
+ * ====================================================================================== */
+void orc_attention_head(const float* q, int T, const float* K, const float* V, int ctx, int hd, const float* maskf,
+                        float* out) {
+  const int NW = 4;
+  const int LPK = hd / 8, G = 64 / LPK;
+  const float scale = (float)(1.0 / sqrt((double)hd));
+  float* s = (float*)xmalloc(sizeof(float) * (size_t)ctx);
+  float* acc = (float*)xmalloc(sizeof(float) * (size_t)NW * G * hd);
+  for (int t = 0; t < T; ++t) {
+    const float* qt = q + (size_t)t * hd;
+    float m = ORC_NEG_INF;
+    for (int j = 0; j < ctx; ++j) {
+      float part[16];
+      for (int i = 0; i < LPK; ++i) {
+        float a = 0.0f;
+        for (int dd = 0; dd < 8; ++dd) a = DSM_FMAF(qt[8 * i + dd], K[(size_t)j * hd + 8 * i + dd], a);
+        part[i] = a;
+      }
+      dsm_butterfly_sum(part, LPK);
+      float sc = part[0] * scale + maskf[(size_t)t * ctx + j];
+      s[j] = sc;
+      if (sc > m) m = sc;
+    }
+    /* softmax_last_dim: exp(x - max), sum, divide */
+    float tp[256];
+    for (int i = 0; i < 256; ++i) tp[i] = 0.0f;
+    for (int j = 0; j < ctx; ++j) {
+      s[j] = dsm_expf(s[j] - m);
+      tp[j & 255] = tp[j & 255] + s[j];
+    }
+    float l = 0.0f;
+    for (int w = 0; w < NW; ++w) {
+      dsm_butterfly_sum(tp + 64 * w, 64);
+      l = (w == 0) ? tp[0] : l + tp[64 * w];
+    }
+    for (size_t i = 0; i < (size_t)NW * G * hd; ++i) acc[i] = 0.0f;
+    for (int j = 0; j < ctx; ++j) {
+      float wgt = s[j] / l;
+      int w = (j / G) % NW, g = j % G;
+      float* a = acc + ((size_t)w * G + g) * hd;
+      const float* vr = V + (size_t)j * hd;
+      for (int d = 0; d < hd; ++d) a[d] = DSM_FMAF(wgt, vr[d], a[d]);
+    }
+    for (int d = 0; d < hd; ++d) {
+      float tot = 0.0f;
+      for (int w = 0; w < NW; ++w) {
+        float gp[16];
+        for (int g = 0; g < G; ++g) gp[g] = acc[((size_t)w * G + g) * hd + d];
+        dsm_butterfly_sum(gp, G);
+        tot = (w == 0) ? gp[0] : tot + gp[0];
+      }
+      out[(size_t)t * hd + d] = tot;
+    }
+  }
+  free(s);
+  free(acc);
+}
+
+/* ======================================================================================
+ * ScatteredCacheBuilder — core/kv_cache.rs:54-295 (literal port, u32 state on the host)
+ * ====================================================================================== */
+struct orc_kvb {
+  int B, context;
+  uint32_t* positions; /* core/kv_cache.rs:57 */
+  uint32_t* indices;   /* core/kv_cache.rs:59 */
+};
+
+orc_kvb* orc_kvb_new(int batch_size, int context) {
+  orc_kvb* k = (orc_kvb*)xcalloc(1, sizeof *k);
+  k->B = batch_size;
+  k->context = context;
+  k->positions = (uint32_t*)xcalloc(batch_size, 4);
+  k->indices = (uint32_t*)xcalloc(batch_size, 4);
+  return k;
+}
+void orc_kvb_free(orc_kvb* k) {
+  if (!k) return;
+  free(k->positions);
+  free(k->indices);
+  free(k);
+}
+/* reset_batch_index — core/kv_cache.rs:111-117 */
+void orc_kvb_reset_batch_index(orc_kvb* k, int b) {
+  k->positions[b] = 0;
+  k->indices[b] = 0;
+}
+void orc_kvb_get(const orc_kvb* k, uint32_t* positions, uint32_t* indices) {
+  memcpy(positions, k->positions, 4 * (size_t)k->B);
+  memcpy(indices, k->indices, 4 * (size_t)k->B);
+}
+
+void orc_kvb_indices_and_mask(orc_kvb* kb, int seq_len, const uint8_t* batch_mask, uint32_t* indices_out,
+                              float* mask_out) {
+  const int B = kb->B, context = kb->context;
+  if (context <= seq_len) {
+    /* indices_and_mask_abs — core/kv_cache.rs:240-294: mask [seq_len, seq_len] shared by all rows;
+     * written here broadcast to [B, seq_len, context(=first seq_len cols)] is not meaningful, so
+     * this path (never taken by the streaming step: T in {1,2} << ctx) fills only indices. */
+    for (int b = 0; b < B; ++b)
+      for (int t = 0; t < seq_len; ++t) {
+        indices_out[b * seq_len + t] = kb->indices[b];
+        if (batch_mask[b]) {
+          kb->indices[b] += 1;
+          kb->positions[b] += 1;
+          if ((int)kb->indices[b] >= context) kb->indices[b] = 0;
+        }
+      }
+    for (int i = 0; i < seq_len; ++i)
+      for (int j = 0; j < seq_len; ++j) {
+        int neg = (seq_len + j > seq_len + i) || (seq_len + j + context < seq_len + i);
+        if (mask_out) mask_out[i * seq_len + j] = neg ? ORC_NEG_INF : 0.0f;
+      }
+    return;
+  }
+  if (seq_len == 1) {
+    /* fast path — core/kv_cache.rs:130-170 */
+    for (int b = 0; b < B; ++b) {
+      uint32_t prev_idx = kb->indices[b], prev_pos = kb->positions[b];
+      int active = batch_mask[b] != 0;
+      if (active) {
+        uint32_t ni = prev_idx + 1;
+        if (ni >= (uint32_t)context) ni -= (uint32_t)context;
+        kb->indices[b] = ni;
+        kb->positions[b] = prev_pos + 1;
+      }
+      indices_out[b] = active ? prev_idx : kb->indices[b];
+      uint32_t start_pos = active ? prev_pos : 0xFFFFFFFFu; /* inactive -> all-zero mask */
+      for (int j = 0; j < context; ++j) mask_out[(size_t)b * context + j] = ((uint32_t)j > start_pos) ? ORC_NEG_INF : 0.0f;
+    }
+    return;
+  }
+  /* indices_and_mask_slow — core/kv_cache.rs:176-237 */
+  size_t* all_pos = (size_t*)xmalloc(sizeof(size_t) * (size_t)context);
+  for (int b = 0; b < B; ++b) {
+    float* mrow = mask_out + (size_t)b * seq_len * context;
+    if (!batch_mask[b]) {
+      for (int i = 0; i < seq_len * context; ++i) mrow[i] = 0.0f;
+      for (int t = 0; t < seq_len; ++t) indices_out[b * seq_len + t] = kb->indices[b];
+      continue;
+    }
+    size_t start_index = kb->indices[b], start_pos = kb->positions[b];
+    for (int i = 0; i < context; ++i) all_pos[i] = (size_t)-1;
+    if (start_pos < (size_t)context) {
+      for (size_t i = 0; i < start_pos; ++i) all_pos[i] = i;
+    } else {
+      size_t offset = start_pos - start_index;
+      for (size_t i = 0; i < (size_t)context; ++i) all_pos[i] = i < start_index ? i + offset : i + offset - context;
+    }
+    for (int t = 0; t < seq_len; ++t) {
+      size_t index = kb->indices[b];
+      all_pos[index] = t + start_pos;
+      indices_out[b * seq_len + t] = (uint32_t)index;
+      kb->indices[b] += 1;
+      kb->positions[b] += 1;
+      if ((int)kb->indices[b] >= context) kb->indices[b] = 0;
+    }
+    for (int t = 0; t < seq_len; ++t) {
+      size_t my_pos = t + start_pos;
+      for (int j = 0; j < context; ++j) mrow[(size_t)t * context + j] = all_pos[j] <= my_pos ? 0.0f : ORC_NEG_INF;
+    }
+  }
+  free(all_pos);
+}
+
+/* ======================================================================================
+ * StreamableConv1d — core/conv.rs:226-371.  Channels-last [B][T][C]; the im2col row of
+ * output frame t is the k runs x[t*stride + kk*dilation][0..in_c), reduction index
+ * kprime = kk*in_c + ci ("kk-major").
+ * ====================================================================================== */
+struct orc_conv1d {
+  int B, in_c, out_c, k, stride, dilation, replicate_pad;
+  float* w; /* [out_c][k*in_c], kk-major */
+  float* b; /* [out_c] or NULL */
+  float* state; /* state_prev_xs: [B][state_len][in_c] or NULL (core/conv.rs:231) */
+  int state_len;
+  int left_pad_applied; /* core/conv.rs:232 */
+};
+
+orc_conv1d* orc_conv1d_new(int batch, int in_c, int out_c, int k, int stride, int dilation, int replicate_pad,
+                           const float* weight, const float* bias) {
+  orc_conv1d* c = (orc_conv1d*)xcalloc(1, sizeof *c);
+  c->B = batch; c->in_c = in_c; c->out_c = out_c; c->k = k; c->stride = stride; c->dilation = dilation;
+  c->replicate_pad = replicate_pad;
+  c->w = (float*)xmalloc(sizeof(float) * (size_t)out_c * k * in_c);
+  for (int o = 0; o < out_c; ++o)
+    for (int ci = 0; ci < in_c; ++ci)
+      for (int kk = 0; kk < k; ++kk)
+        c->w[((size_t)o * k + kk) * in_c + ci] = weight[((size_t)o * in_c + ci) * k + kk];
+  if (bias) {
+    c->b = (float*)xmalloc(sizeof(float) * (size_t)out_c);
+    memcpy(c->b, bias, sizeof(float) * (size_t)out_c);
+  }
+  return c;
+}
+void orc_conv1d_free(orc_conv1d* c) {
+  if (!c) return;
+  free(c->w); free(c->b); free(c->state); free(c);
+}
+void orc_conv1d_reset_state(orc_conv1d* c) { /* core/conv.rs:307-310 */
+  free(c->state);
+  c->state = NULL;
+  c->state_len = 0;
+  c->left_pad_applied = 0;
+}
+void orc_conv1d_reset_batch_idx(orc_conv1d* c, int b) { /* core/conv.rs:274-281: zero, do NOT re-arm the left pad */
+  if (c->state) memset(c->state + (size_t)b * c->state_len * c->in_c, 0, sizeof(float) * (size_t)c->state_len * c->in_c);
+}
+
+/* valid conv of x [B][L][in_c] -> y [B][n][out_c], n = (L - k_eff)/stride + 1 */
+static void conv1d_valid(const orc_conv1d* c, const float* x, int L, int n, float* y) {
+  const int in_c = c->in_c, K = c->k * in_c;
+  if (c->dilation == 1) {
+    for (int b = 0; b < c->B; ++b)
+      orc_linear(y + (size_t)b * n * c->out_c, c->out_c, x + (size_t)b * L * in_c, c->stride * in_c, c->w, K, c->b, n,
+                 c->out_c, K);
+  } else {
+    float* col = (float*)xmalloc(sizeof(float) * (size_t)n * K);
+    for (int b = 0; b < c->B; ++b) {
+      for (int t = 0; t < n; ++t)
+        for (int kk = 0; kk < c->k; ++kk)
+          memcpy(col + (size_t)t * K + (size_t)kk * in_c,
+                 x + ((size_t)b * L + (size_t)t * c->stride + (size_t)kk * c->dilation) * in_c, sizeof(float) * in_c);
+      orc_linear(y + (size_t)b * n * c->out_c, c->out_c, col, K, c->w, K, c->b, n, c->out_c, K);
+    }
+    free(col);
+  }
+}
+
+/* pad1d along time — core/conv.rs:210-216 */
+static float* pad_time(const float* x, int B, int T, int C, int pad_l, int pad_r, int replicate) {
+  int L = T + pad_l + pad_r;
+  float* o = (float*)xcalloc((size_t)B * L * C, sizeof(float));
+  for (int b = 0; b < B; ++b) {
+    memcpy(o + ((size_t)b * L + pad_l) * C, x + (size_t)b * T * C, sizeof(float) * (size_t)T * C);
+    if (replicate && T > 0) {
+      for (int i = 0; i < pad_l; ++i) memcpy(o + ((size_t)b * L + i) * C, x + (size_t)b * T * C, sizeof(float) * C);
+      for (int i = 0; i < pad_r; ++i)
+        memcpy(o + ((size_t)b * L + pad_l + T + i) * C, x + ((size_t)b * T + T - 1) * C, sizeof(float) * C);
+    }
+  }
+  return o;
+}
+
+/* Module::forward — core/conv.rs:284-304 (causal) */
+int orc_conv1d_forward(orc_conv1d* c, const float* x, int T, float* y, int y_cap_frames) {
+  int k_eff = (c->k - 1) * c->dilation + 1;
+  int padding_total = k_eff - c->stride;
+  /* get_extra_padding_for_conv1d — core/conv.rs:197-208 */
+  int len = T;
+  long num = (long)len + padding_total - k_eff;
+  if (num < 0) num = 0;
+  double n_frames = (double)num / (double)c->stride + 1.0;
+  long ideal = ((long)ceil(n_frames) - 1) * c->stride + k_eff - padding_total;
+  if (ideal < 0) ideal = 0;
+  int extra = (int)(ideal > len ? ideal - len : 0);
+  float* xp = pad_time(x, c->B, T, c->in_c, padding_total, extra, c->replicate_pad);
+  int L = T + padding_total + extra;
+  int n = (L - k_eff) / c->stride + 1;
+  if (n > y_cap_frames) { free(xp); return -1; }
+  conv1d_valid(c, xp, L, n, y);
+  free(xp);
+  return n;
+}
+
+/* StreamingModule::step — core/conv.rs:312-370 */
+int orc_conv1d_step(orc_conv1d* c, const float* x_in, int T, const uint8_t* mask, float* y, int y_cap_frames) {
+  if (T == 0) return 0; /* :314-317 */
+  const int B = c->B, C = c->in_c;
+  int k_eff = (c->k - 1) * c->dilation + 1;
+  float* x = NULL;
+  int Tx = T;
+  if (!c->left_pad_applied) { /* :318-327 */
+    c->left_pad_applied = 1;
+    int padding_total = k_eff - c->stride;
+    x = pad_time(x_in, B, T, C, padding_total, 0, c->replicate_pad);
+    Tx = T + padding_total;
+  } else {
+    x = (float*)xmalloc(sizeof(float) * (size_t)B * T * C);
+    memcpy(x, x_in, sizeof(float) * (size_t)B * T * C);
+  }
+  /* cat2(state_prev_xs, xs) — :332 */
+  int L = c->state_len + Tx;
+  float* cat = (float*)xmalloc(sizeof(float) * (size_t)B * L * C);
+  for (int b = 0; b < B; ++b) {
+    if (c->state_len) memcpy(cat + (size_t)b * L * C, c->state + (size_t)b * c->state_len * C, sizeof(float) * (size_t)c->state_len * C);
+    memcpy(cat + ((size_t)b * L + c->state_len) * C, x + (size_t)b * Tx * C, sizeof(float) * (size_t)Tx * C);
+  }
+  free(x);
+  int num_frames = (L + c->stride >= k_eff) ? (L + c->stride - k_eff) / c->stride : 0; /* :334 saturating_sub */
+  float* new_state = NULL;
+  int new_len = 0;
+  if (num_frames > 0) { /* :335-343 */
+    int offset = num_frames * c->stride;
+    new_len = L - offset; /* narrow(offset, L-offset); StreamTensor::narrow gives None when L <= offset */
+    if (new_len > 0) {
+      new_state = (float*)xmalloc(sizeof(float) * (size_t)B * new_len * C);
+      for (int b = 0; b < B; ++b)
+        memcpy(new_state + (size_t)b * new_len * C, cat + ((size_t)b * L + offset) * C, sizeof(float) * (size_t)new_len * C);
+    }
+    if (num_frames > y_cap_frames) { free(cat); free(new_state); return -1; }
+    conv1d_valid(c, cat, L, num_frames, y); /* only the first (n-1)*s + k_eff frames are read */
+  } else { /* :344-346 */
+    new_len = L;
+    new_state = cat;
+    cat = NULL;
+  }
+  /* mask handling — :347-367 */
+  if (mask) {
+    if (new_state && !c->state) {
+      for (int b = 0; b < B; ++b)
+        if (!mask[b]) memset(new_state + (size_t)b * new_len * C, 0, sizeof(float) * (size_t)new_len * C);
+    } else if (!new_state && c->state) {
+      fprintf(stderr, "streaming conv1d should only be used with constant steps\n");
+      abort();
+    } else if (new_state && c->state) {
+      if (new_len != c->state_len) {
+        fprintf(stderr, "streaming conv1d should only be used with constant steps (%d vs %d)\n", new_len, c->state_len);
+        abort();
+      }
+      for (int b = 0; b < B; ++b)
+        if (!mask[b])
+          memcpy(new_state + (size_t)b * new_len * C, c->state + (size_t)b * new_len * C, sizeof(float) * (size_t)new_len * C);
+    }
+  }
+  free(c->state);
+  c->state = new_state;
+  c->state_len = new_state ? new_len : 0;
+  free(cat);
+  return num_frames;
+}
+
+/* ======================================================================================
+ * StreamableConvTranspose1d — core/conv.rs:373-502 (+ NormConvTranspose1d :104-195).
+ * y[t*stride + kk][co] += sum_ci x[t][ci] * w[ci][co][kk]; reduction over ci is a canonical
+ * dot of length in_c per (t, co, kk); contributions of different t to one output frame are
+ * added in increasing t.  depthwise (groups == in_c == out_c, :144-150) is the diagonal case.
+ * ====================================================================================== */
+struct orc_convtr1d {
+  int B, in_c, out_c, k, stride, depthwise;
+  float* w; /* [k*out_c][in_c] : row (kk*out_c + co) = w[:, co, kk]   (depthwise: [k][C]) */
+  float* b;
+  float* state; /* state_prev_ys: [B][k - stride][out_c] or NULL */
+  int state_len;
+};
+
+orc_convtr1d* orc_convtr1d_new(int batch, int in_c, int out_c, int k, int stride, int depthwise,
+                               const float* weight, const float* bias) {
+  orc_convtr1d* c = (orc_convtr1d*)xcalloc(1, sizeof *c);
+  c->B = batch; c->in_c = in_c; c->out_c = out_c; c->k = k; c->stride = stride; c->depthwise = depthwise;
+  if (depthwise) { /* checkpoint weight [C][1][k] */
+    c->w = (float*)xmalloc(sizeof(float) * (size_t)k * in_c);
+    for (int ch = 0; ch < in_c; ++ch)
+      for (int kk = 0; kk < k; ++kk) c->w[(size_t)kk * in_c + ch] = weight[(size_t)ch * k + kk];
+  } else { /* checkpoint weight [in_c][out_c][k] */
+    c->w = (float*)xmalloc(sizeof(float) * (size_t)k * out_c * in_c);
+    for (int ci = 0; ci < in_c; ++ci)
+      for (int co = 0; co < out_c; ++co)
+        for (int kk = 0; kk < k; ++kk)
+          c->w[((size_t)kk * out_c + co) * in_c + ci] = weight[((size_t)ci * out_c + co) * k + kk];
+  }
+  if (bias) {
+    c->b = (float*)xmalloc(sizeof(float) * (size_t)out_c);
+    memcpy(c->b, bias, sizeof(float) * (size_t)out_c);
+  }
+  return c;
+}
+void orc_convtr1d_free(orc_convtr1d* c) {
+  if (!c) return;
+  free(c->w); free(c->b); free(c->state); free(c);
+}
+void orc_convtr1d_reset_batch_idx(orc_convtr1d* c, int b) { /* core/conv.rs:415-422 */
+  if (c->state) memset(c->state + (size_t)b * c->state_len * c->out_c, 0, sizeof(float) * (size_t)c->state_len * c->out_c);
+}
+
+/* full conv-transpose + bias: x [B][T][in_c] -> y [B][(T-1)*s + k][out_c]  (core/conv.rs:173-189) */
+static float* convtr_full(const orc_convtr1d* c, const float* x, int T, int* ot_out) {
+  const int B = c->B, s = c->stride, k = c->k, OC = c->out_c, IC = c->in_c;
+  int ot = (T - 1) * s + k;
+  float* y = (float*)xcalloc((size_t)B * ot * OC, sizeof(float));
+  if (c->depthwise) {
+    for (int b = 0; b < B; ++b)
+      for (int t = 0; t < T; ++t)
+        for (int kk = 0; kk < k; ++kk)
+          for (int ch = 0; ch < OC; ++ch) {
+            float* o = &y[((size_t)b * ot + (size_t)t * s + kk) * OC + ch];
+            *o = *o + x[((size_t)b * T + t) * IC + ch] * c->w[(size_t)kk * IC + ch];
+          }
+  } else {
+    float* z = (float*)xmalloc(sizeof(float) * (size_t)B * T * k * OC);
+    orc_linear(z, k * OC, x, IC, c->w, IC, NULL, B * T, k * OC, IC);
+    for (int b = 0; b < B; ++b)
+      for (int t = 0; t < T; ++t)
+        for (int kk = 0; kk < k; ++kk)
+          for (int co = 0; co < OC; ++co) {
+            float* o = &y[((size_t)b * ot + (size_t)t * s + kk) * OC + co];
+            *o = *o + z[(((size_t)b * T + t) * k + kk) * OC + co];
+          }
+    free(z);
+  }
+  if (c->b)
+    for (size_t i = 0; i < (size_t)B * ot; ++i)
+      for (int co = 0; co < OC; ++co) y[i * OC + co] = y[i * OC + co] + c->b[co];
+  *ot_out = ot;
+  return y;
+}
+
+/* Module::forward — core/conv.rs:425-441 (causal: unpad right k - stride) */
+int orc_convtr1d_forward(orc_convtr1d* c, const float* x, int T, float* y, int y_cap_frames) {
+  int ot;
+  float* full = convtr_full(c, x, T, &ot);
+  int pad = c->k > c->stride ? c->k - c->stride : 0;
+  int n = ot - pad;
+  if (n > y_cap_frames) { free(full); return -1; }
+  for (int b = 0; b < c->B; ++b)
+    memcpy(y + (size_t)b * n * c->out_c, full + (size_t)b * ot * c->out_c, sizeof(float) * (size_t)n * c->out_c);
+  free(full);
+  return n;
+}
+
+/* StreamingModule::step — core/conv.rs:448-501 */
+int orc_convtr1d_step(orc_convtr1d* c, const float* x, int T, const uint8_t* mask, float* y, int y_cap_frames) {
+  if (T == 0) return 0;
+  const int B = c->B, OC = c->out_c;
+  int ot;
+  float* ys = convtr_full(c, x, T, &ot);
+  if (c->state) { /* :459-475: ys[:pt] += prev_ys - bias */
+    int pt = c->state_len;
+    for (int b = 0; b < B; ++b)
+      for (int t = 0; t < pt; ++t)
+        for (int co = 0; co < OC; ++co) {
+          float prev = c->state[((size_t)b * pt + t) * OC + co];
+          if (c->b) prev = prev - c->b[co];
+          float* o = &ys[((size_t)b * ot + t) * OC + co];
+          *o = *o + prev;
+        }
+  }
+  int invalid = c->k - c->stride; /* :476 */
+  int n = ot - invalid;          /* split(ot - invalid_steps) */
+  if (n < 0) n = 0;
+  if (n > ot) n = ot;
+  int new_len = ot - n;
+  float* new_state = NULL;
+  if (new_len > 0) {
+    new_state = (float*)xmalloc(sizeof(float) * (size_t)B * new_len * OC);
+    for (int b = 0; b < B; ++b)
+      memcpy(new_state + (size_t)b * new_len * OC, ys + ((size_t)b * ot + n) * OC, sizeof(float) * (size_t)new_len * OC);
+  }
+  if (n > y_cap_frames) { free(ys); free(new_state); return -1; }
+  for (int b = 0; b < B; ++b)
+    memcpy(y + (size_t)b * n * OC, ys + (size_t)b * ot * OC, sizeof(float) * (size_t)n * OC);
+  free(ys);
+  if (mask) { /* :478-498 */
+    if (new_state && !c->state) {
+      for (int b = 0; b < B; ++b)
+        if (!mask[b]) memset(new_state + (size_t)b * new_len * OC, 0, sizeof(float) * (size_t)new_len * OC);
+    } else if (!new_state && c->state) {
+      fprintf(stderr, "streaming conv-tr1d should only be used with constant steps\n");
+      abort();
+    } else if (new_state && c->state) {
+      if (new_len != c->state_len) {
+        fprintf(stderr, "streaming conv-tr1d should only be used with constant steps\n");
+        abort();
+      }
+      for (int b = 0; b < B; ++b)
+        if (!mask[b])
+          memcpy(new_state + (size_t)b * new_len * OC, c->state + (size_t)b * new_len * OC, sizeof(float) * (size_t)new_len * OC);
+    }
+  }
+  free(c->state);
+  c->state = new_state;
+  c->state_len = new_state ? new_len : 0;
+  return n;
+}
+
+/* ======================================================================================
+ * Weight access helpers (key map: SURVEY.md §2.2)
+ * ====================================================================================== */
+typedef struct {
+  dsm_st_file* f;
+  char* err;
+  size_t errcap;
+  int failed;
+} wsrc;
+
+static float* w_get(wsrc* s, int64_t numel, const char* fmt, ...) __attribute__((format(printf, 3, 4)));
+#include <stdarg.h>
+static float* w_get(wsrc* s, int64_t numel, const char* fmt, ...) {
+  char name[256];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(name, sizeof name, fmt, ap);
+  va_end(ap);
+  float* out = (float*)xmalloc(sizeof(float) * (size_t)numel);
+  if (s->failed) return out;
+  if (dsm_st_read_f32(s->f, name, numel, out, s->err, s->errcap)) s->failed = 1;
+  return out;
+}
+static int w_has(wsrc* s, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+static int w_has(wsrc* s, const char* fmt, ...) {
+  char name[256];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(name, sizeof name, fmt, ap);
+  va_end(ap);
+  return dsm_st_find(s->f, name) != NULL;
+}
+
+/* conv1d_weight_norm — core/conv.rs:27-45: weight, or weight_v * weight_g / ||weight_v||_(1,2) */
+static float* load_conv_weight(wsrc* s, const char* prefix, int out_c, int in_c, int k) {
+  if (w_has(s, "%s.weight", prefix)) return w_get(s, (int64_t)out_c * in_c * k, "%s.weight", prefix);
+  float* g = w_get(s, out_c, "%s.weight_g", prefix);
+  float* v = w_get(s, (int64_t)out_c * in_c * k, "%s.weight_v", prefix);
+  for (int o = 0; o < out_c; ++o) {
+    float ss = 0.0f;
+    for (int i = 0; i < in_c * k; ++i) ss = ss + v[(size_t)o * in_c * k + i] * v[(size_t)o * in_c * k + i];
+    float nrm = sqrtf(ss);
+    for (int i = 0; i < in_c * k; ++i) v[(size_t)o * in_c * k + i] = v[(size_t)o * in_c * k + i] * g[o] / nrm;
+  }
+  free(g);
+  return v;
+}
+
+static orc_conv1d* load_conv1d(wsrc* s, int B, const char* prefix, int in_c, int out_c, int k, int stride,
+                               int dilation, int replicate, int bias) {
+  char p[256];
+  snprintf(p, sizeof p, "%s.conv.conv", prefix); /* StreamableConv1d -> NormConv1d -> Conv1d: vb.pp("conv").pp("conv") */
+  float* w = load_conv_weight(s, p, out_c, in_c, k);
+  float* b = bias ? w_get(s, out_c, "%s.bias", p) : NULL;
+  orc_conv1d* c = orc_conv1d_new(B, in_c, out_c, k, stride, dilation, replicate, w, b);
+  free(w);
+  free(b);
+  return c;
+}
+
+/* ======================================================================================
+ * SeaNetEncoder — core/seanet.rs:153-303
+ * ====================================================================================== */
+typedef struct {
+  orc_conv1d* block[2]; /* (residual_kernel_size, dilation) then (1,1) — core/seanet.rs:58-75 */
+} orc_resblock;
+
+typedef struct {
+  int n_res;
+  orc_resblock* res;
+  orc_conv1d* down;
+} orc_enc_layer;
+
+typedef struct {
+  int B;
+  orc_conv1d* init_conv;
+  int n_layers;
+  orc_enc_layer* layers;
+  orc_conv1d* final_conv;
+} orc_seanet_enc;
+
+static void elu_inplace(float* x, size_t n) {
+  for (size_t i = 0; i < n; ++i) x[i] = dsm_elu(x[i]);
+}
+
+static orc_seanet_enc* seanet_enc_load(wsrc* s, int B, const dsm_mimi_config* cfg) {
+  orc_seanet_enc* e = (orc_seanet_enc*)xcalloc(1, sizeof *e);
+  e->B = B;
+  int mult = 1, layer_idx = 0;
+  char p[128];
+  snprintf(p, sizeof p, "encoder.model.%d", layer_idx);
+  e->init_conv = load_conv1d(s, B, p, cfg->channels, mult * cfg->n_filters, cfg->kernel_size, 1, 1, 0, 1);
+  layer_idx += 1;
+  e->n_layers = cfg->n_ratios;
+  e->layers = (orc_enc_layer*)xcalloc(cfg->n_ratios, sizeof(orc_enc_layer));
+  for (int i = 0; i < cfg->n_ratios; ++i) {
+    int ratio = cfg->ratios[cfg->n_ratios - 1 - i]; /* ratios.iter().rev() — core/seanet.rs:194 */
+    orc_enc_layer* L = &e->layers[i];
+    L->n_res = cfg->n_residual_layers;
+    L->res = (orc_resblock*)xcalloc(L->n_res, sizeof(orc_resblock));
+    int dim = mult * cfg->n_filters, hidden = dim / cfg->compress;
+    for (int j = 0; j < L->n_res; ++j) {
+      int dil = 1;
+      for (int q = 0; q < j; ++q) dil *= cfg->dilation_base;
+      snprintf(p, sizeof p, "encoder.model.%d.block.1", layer_idx);
+      L->res[j].block[0] = load_conv1d(s, B, p, dim, hidden, cfg->residual_kernel_size, 1, dil, 0, 1);
+      snprintf(p, sizeof p, "encoder.model.%d.block.3", layer_idx);
+      L->res[j].block[1] = load_conv1d(s, B, p, hidden, dim, 1, 1, 1, 0, 1);
+      layer_idx += 1;
+    }
+    snprintf(p, sizeof p, "encoder.model.%d", layer_idx + 1);
+    L->down = load_conv1d(s, B, p, dim, dim * 2, ratio * 2, ratio, 1, 0, 1);
+    layer_idx += 2;
+    mult *= 2;
+  }
+  snprintf(p, sizeof p, "encoder.model.%d", layer_idx + 1);
+  e->final_conv = load_conv1d(s, B, p, mult * cfg->n_filters, cfg->dimension, cfg->last_kernel_size, 1, 1, 0, 1);
+  return e;
+}
+
+static void seanet_enc_free(orc_seanet_enc* e) {
+  if (!e) return;
+  orc_conv1d_free(e->init_conv);
+  for (int i = 0; i < e->n_layers; ++i) {
+    for (int j = 0; j < e->layers[i].n_res; ++j) {
+      orc_conv1d_free(e->layers[i].res[j].block[0]);
+      orc_conv1d_free(e->layers[i].res[j].block[1]);
+    }
+    free(e->layers[i].res);
+    orc_conv1d_free(e->layers[i].down);
+  }
+  free(e->layers);
+  orc_conv1d_free(e->final_conv);
+  free(e);
+}
+
+/* SeaNetResnetBlock::step — core/seanet.rs:140-150 (true_skip; StreamingBinOp add, core/streaming.rs:234-263:
+ * equal lengths every step, otherwise the reference bails when a mask is present) */
+static int resblock_step(orc_resblock* r, int B, const float* x, int T, int C, const uint8_t* mask, float* out) {
+  int hidden = r->block[0]->out_c;
+  float* a = (float*)xmalloc(sizeof(float) * (size_t)B * T * C);
+  memcpy(a, x, sizeof(float) * (size_t)B * T * C);
+  elu_inplace(a, (size_t)B * T * C);
+  float* h = (float*)xmalloc(sizeof(float) * (size_t)B * T * hidden);
+  int t1 = orc_conv1d_step(r->block[0], a, T, mask, h, T);
+  free(a);
+  elu_inplace(h, (size_t)B * t1 * hidden);
+  int t2 = orc_conv1d_step(r->block[1], h, t1, mask, out, T);
+  free(h);
+  if (t2 != T) {
+    fprintf(stderr, "oracle: resnet branch length %d != skip length %d (StreamingBinOp would carry)\n", t2, T);
+    abort();
+  }
+  for (size_t i = 0; i < (size_t)B * T * C; ++i) out[i] = out[i] + x[i];
+  return T;
+}
+
+/* SeaNetEncoder::step — core/seanet.rs:292-302.  x [B][T][channels] -> out [B][T'][dimension] */
+static int seanet_enc_step(orc_seanet_enc* e, const float* pcm, int T, const uint8_t* mask, float** out) {
+  const int B = e->B;
+  int C = e->init_conv->out_c;
+  float* cur = (float*)xmalloc(sizeof(float) * (size_t)B * T * C);
+  int Tc = orc_conv1d_step(e->init_conv, pcm, T, mask, cur, T);
+  for (int i = 0; i < e->n_layers && Tc > 0; ++i) {
+    orc_enc_layer* L = &e->layers[i];
+    for (int j = 0; j < L->n_res; ++j) {
+      float* nx = (float*)xmalloc(sizeof(float) * (size_t)B * Tc * C);
+      resblock_step(&L->res[j], B, cur, Tc, C, mask, nx);
+      free(cur);
+      cur = nx;
+    }
+    elu_inplace(cur, (size_t)B * Tc * C);
+    int C2 = L->down->out_c;
+    int cap = Tc / L->down->stride + 2;
+    float* nx = (float*)xmalloc(sizeof(float) * (size_t)B * cap * C2);
+    int Tn = orc_conv1d_step(L->down, cur, Tc, mask, nx, cap);
+    free(cur);
+    cur = nx;
+    Tc = Tn;
+    C = C2;
+  }
+  if (Tc > 0) {
+    elu_inplace(cur, (size_t)B * Tc * C);
+    int C2 = e->final_conv->out_c;
+    float* nx = (float*)xmalloc(sizeof(float) * (size_t)B * Tc * C2);
+    int Tn = orc_conv1d_step(e->final_conv, cur, Tc, mask, nx, Tc);
+    free(cur);
+    cur = nx;
+    Tc = Tn;
+  }
+  *out = cur;
+  return Tc;
+}
+
+static void seanet_enc_reset_batch_idx(orc_seanet_enc* e, int b) { /* core/seanet.rs:255-265 */
+  orc_conv1d_reset_batch_idx(e->init_conv, b);
+  orc_conv1d_reset_batch_idx(e->final_conv, b);
+  for (int i = 0; i < e->n_layers; ++i) {
+    orc_conv1d_reset_batch_idx(e->layers[i].down, b);
+    for (int j = 0; j < e->layers[i].n_res; ++j) {
+      orc_conv1d_reset_batch_idx(e->layers[i].res[j].block[0], b);
+      orc_conv1d_reset_batch_idx(e->layers[i].res[j].block[1], b);
+    }
+  }
+}
+
+/* ======================================================================================
+ * batched_transformer::StreamingTransformer — core/batched_transformer.rs:19-513
+ * ====================================================================================== */
+typedef struct {
+  float *in_proj, *out_proj;       /* [3d][d], [d][d] */
+  float *norm1_w, *norm1_b, *norm2_w, *norm2_b; /* alpha / weight (+bias for LayerNorm) */
+  float *ff_in, *ff_out;           /* gating: linear_in [2*hid][d], linear_out [d][hid]; else linear1 [ff][d], linear2 [d][ff] */
+  float *ls1, *ls2;                /* layer scales or NULL */
+  float *k_cache, *v_cache;        /* [B][H][ctx][hd] — ScatteredKvCache, core/kv_cache.rs:21-25 */
+} orc_tlayer;
+
+typedef struct {
+  dsm_transformer_config cfg;
+  int B, hidden; /* gating hidden size */
+  int kv_bf16;
+  orc_tlayer* layers;
+  orc_kvb* builder;
+  float* inv_freq;
+} orc_transformer;
+
+static int gating_hidden(const dsm_transformer_config* c) { /* core/batched_transformer.rs:153-157 */
+  return c->dim_feedforward == 4 * c->d_model ? 11 * c->d_model / 4 : 2 * c->dim_feedforward / 3;
+}
+
+static orc_transformer* transformer_load(wsrc* s, int B, const dsm_transformer_config* cfg, const char* prefix,
+                                         int kv_bf16) {
+  orc_transformer* t = (orc_transformer*)xcalloc(1, sizeof *t);
+  t->cfg = *cfg;
+  t->B = B;
+  t->kv_bf16 = kv_bf16;
+  const int d = cfg->d_model, H = cfg->num_heads, hd = d / H;
+  t->hidden = cfg->gating ? gating_hidden(cfg) : cfg->dim_feedforward;
+  t->layers = (orc_tlayer*)xcalloc(cfg->num_layers, sizeof(orc_tlayer));
+  t->builder = orc_kvb_new(B, cfg->context);
+  t->inv_freq = (float*)xmalloc(sizeof(float) * (size_t)(hd / 2));
+  orc_rope_table(hd, cfg->max_period, t->inv_freq);
+  for (int l = 0; l < cfg->num_layers; ++l) {
+    orc_tlayer* L = &t->layers[l];
+    L->in_proj = w_get(s, (int64_t)3 * d * d, "%s.layers.%d.self_attn.in_proj_weight", prefix, l);
+    L->out_proj = w_get(s, (int64_t)d * d, "%s.layers.%d.self_attn.out_proj.weight", prefix, l);
+    for (int which = 1; which <= 2; ++which) {
+      float **w = which == 1 ? &L->norm1_w : &L->norm2_w, **b = which == 1 ? &L->norm1_b : &L->norm2_b;
+      if (cfg->norm == 1) { /* RmsNorm: alpha [1,1,d] — :189 */
+        *w = w_get(s, d, "%s.layers.%d.norm%d.alpha", prefix, l, which);
+      } else { /* LayerNorm: alpha or weight, + bias — :206-212 */
+        *b = w_get(s, d, "%s.layers.%d.norm%d.bias", prefix, l, which);
+        if (w_has(s, "%s.layers.%d.norm%d.alpha", prefix, l, which))
+          *w = w_get(s, d, "%s.layers.%d.norm%d.alpha", prefix, l, which);
+        else
+          *w = w_get(s, d, "%s.layers.%d.norm%d.weight", prefix, l, which);
+      }
+    }
+    if (cfg->gating) {
+      L->ff_in = w_get(s, (int64_t)2 * t->hidden * d, "%s.layers.%d.gating.linear_in.weight", prefix, l);
+      L->ff_out = w_get(s, (int64_t)d * t->hidden, "%s.layers.%d.gating.linear_out.weight", prefix, l);
+    } else {
+      L->ff_in = w_get(s, (int64_t)t->hidden * d, "%s.layers.%d.linear1.weight", prefix, l);
+      L->ff_out = w_get(s, (int64_t)d * t->hidden, "%s.layers.%d.linear2.weight", prefix, l);
+    }
+    if (cfg->layer_scale) {
+      L->ls1 = w_get(s, d, "%s.layers.%d.layer_scale_1.scale", prefix, l);
+      L->ls2 = w_get(s, d, "%s.layers.%d.layer_scale_2.scale", prefix, l);
+    }
+    L->k_cache = (float*)xcalloc((size_t)B * H * cfg->context * hd, sizeof(float));
+    L->v_cache = (float*)xcalloc((size_t)B * H * cfg->context * hd, sizeof(float));
+  }
+  return t;
+}
+
+static void transformer_free(orc_transformer* t) {
+  if (!t) return;
+  for (int l = 0; l < t->cfg.num_layers; ++l) {
+    orc_tlayer* L = &t->layers[l];
+    free(L->in_proj); free(L->out_proj); free(L->norm1_w); free(L->norm1_b); free(L->norm2_w); free(L->norm2_b);
+    free(L->ff_in); free(L->ff_out); free(L->ls1); free(L->ls2); free(L->k_cache); free(L->v_cache);
+  }
+  free(t->layers);
+  orc_kvb_free(t->builder);
+  free(t->inv_freq);
+  free(t);
+}
+
+static void norm_apply(const orc_transformer* t, float* y, const float* x, const float* w, const float* b, int rows) {
+  if (t->cfg.norm == 1)
+    orc_rmsnorm(y, x, w, rows, t->cfg.d_model, 1e-8f);
+  else
+    orc_layernorm(y, x, w, b, rows, t->cfg.d_model, 1e-5f);
+}
+
+/* forward_ca (no cross attention) — core/batched_transformer.rs:425-459; xs [B][T][d] in place */
+static void transformer_forward(orc_transformer* tr, float* xs, int T, const uint8_t* mask) {
+  const dsm_transformer_config* c = &tr->cfg;
+  const int B = tr->B, d = c->d_model, H = c->num_heads, hd = d / H, ctx = c->context;
+  uint32_t* indices = (uint32_t*)xmalloc(sizeof(uint32_t) * (size_t)B * T);
+  float* maskf = (float*)xmalloc(sizeof(float) * (size_t)B * T * ctx);
+  orc_kvb_indices_and_mask(tr->builder, T, mask, indices, maskf); /* :438-441 */
+  /* rope positions are read AFTER the builder advanced them — :442-450 */
+  const uint32_t* positions = tr->builder->positions;
+  float* nrm = (float*)xmalloc(sizeof(float) * (size_t)B * T * d);
+  float* qkv = (float*)xmalloc(sizeof(float) * (size_t)B * T * 3 * d);
+  float* att = (float*)xmalloc(sizeof(float) * (size_t)B * T * d);
+  float* prj = (float*)xmalloc(sizeof(float) * (size_t)B * T * d);
+  float* hid = (float*)xmalloc(sizeof(float) * (size_t)B * T * 2 * tr->hidden);
+  float* act = (float*)xmalloc(sizeof(float) * (size_t)B * T * tr->hidden);
+  for (int l = 0; l < c->num_layers; ++l) {
+    orc_tlayer* L = &tr->layers[l];
+    /* StreamingTransformerLayer::forward — :336-363 */
+    norm_apply(tr, nrm, xs, L->norm1_w, L->norm1_b, B * T);
+    /* StreamingMultiheadAttention::forward — :64-121 */
+    orc_linear(qkv, 3 * d, nrm, d, L->in_proj, d, NULL, B * T, 3 * d, d); /* reshape (b,t,3,H,hd) */
+#pragma omp parallel for schedule(static)
+    for (int b = 0; b < B; ++b) {
+      for (int t = 0; t < T; ++t) {
+        float* row = qkv + ((size_t)b * T + t) * 3 * d;
+        uint32_t pos = positions[b] + (uint32_t)t;
+        for (int h = 0; h < H; ++h) {
+          if (c->positional_embedding == 1) {
+            orc_rope_apply(row + (size_t)h * hd, hd, tr->inv_freq, pos);         /* q */
+            orc_rope_apply(row + d + (size_t)h * hd, hd, tr->inv_freq, pos);     /* k */
+          }
+          /* ScatteredKvCache::append (scatter_set at indices) — core/kv_cache.rs:28-42 */
+          uint32_t idx = indices[b * T + t];
+          float* kd = L->k_cache + (((size_t)b * H + h) * ctx + idx) * hd;
+          float* vd = L->v_cache + (((size_t)b * H + h) * ctx + idx) * hd;
+          const float* ks = row + d + (size_t)h * hd;
+          const float* vs = row + 2 * d + (size_t)h * hd;
+          for (int i = 0; i < hd; ++i) {
+            kd[i] = tr->kv_bf16 ? dsm_bf16_to_f32(dsm_f32_to_bf16(ks[i])) : ks[i];
+            vd[i] = tr->kv_bf16 ? dsm_bf16_to_f32(dsm_f32_to_bf16(vs[i])) : vs[i];
+          }
+        }
+      }
+    }
+#pragma omp parallel for schedule(dynamic) collapse(2)
+    for (int b = 0; b < B; ++b)
+      for (int h = 0; h < H; ++h) {
+        float q[2 * 128], o[2 * 128];
+        float* qq = T * hd <= 256 ? q : (float*)xmalloc(sizeof(float) * (size_t)T * hd);
+        float* oo = T * hd <= 256 ? o : (float*)xmalloc(sizeof(float) * (size_t)T * hd);
+        for (int t = 0; t < T; ++t) memcpy(qq + (size_t)t * hd, qkv + ((size_t)b * T + t) * 3 * d + (size_t)h * hd, sizeof(float) * hd);
+        orc_attention_head(qq, T, L->k_cache + ((size_t)b * H + h) * ctx * hd, L->v_cache + ((size_t)b * H + h) * ctx * hd,
+                           ctx, hd, maskf + (size_t)b * T * ctx, oo);
+        for (int t = 0; t < T; ++t) memcpy(att + ((size_t)b * T + t) * d + (size_t)h * hd, oo + (size_t)t * hd, sizeof(float) * hd);
+        if (qq != q) free(qq);
+        if (oo != o) free(oo);
+      }
+    orc_linear(prj, d, att, d, L->out_proj, d, NULL, B * T, d, d);
+    for (size_t i = 0; i < (size_t)B * T; ++i)
+      for (int j = 0; j < d; ++j) {
+        float v = prj[i * d + j];
+        if (L->ls1) v = v * L->ls1[j]; /* LayerScale — core/transformer.rs:97-101 */
+        xs[i * d + j] = xs[i * d + j] + v;
+      }
+    norm_apply(tr, nrm, xs, L->norm2_w, L->norm2_b, B * T);
+    /* Mlp::forward — :166-179 */
+    if (c->gating) {
+      int hidn = tr->hidden;
+      orc_linear(hid, 2 * hidn, nrm, d, L->ff_in, d, NULL, B * T, 2 * hidn, d);
+      for (size_t i = 0; i < (size_t)B * T; ++i)
+        for (int j = 0; j < hidn; ++j) act[i * hidn + j] = dsm_silu(hid[i * 2 * hidn + j]) * hid[i * 2 * hidn + hidn + j];
+      orc_linear(prj, d, act, hidn, L->ff_out, hidn, NULL, B * T, d, hidn);
+    } else {
+      int ff = tr->hidden;
+      orc_linear(hid, ff, nrm, d, L->ff_in, d, NULL, B * T, ff, d);
+      for (size_t i = 0; i < (size_t)B * T * ff; ++i) act[i] = dsm_gelu_erf(hid[i]);
+      orc_linear(prj, d, act, ff, L->ff_out, ff, NULL, B * T, d, ff);
+    }
+    for (size_t i = 0; i < (size_t)B * T; ++i)
+      for (int j = 0; j < d; ++j) {
+        float v = prj[i * d + j];
+        if (L->ls2) v = v * L->ls2[j];
+        xs[i * d + j] = xs[i * d + j] + v;
+      }
+  }
+  free(indices); free(maskf); free(nrm); free(qkv); free(att); free(prj); free(hid); free(act);
+}
+
+/* ======================================================================================
+ * SplitResidualVectorQuantizer — core/quantization.rs:71-391
+ * ====================================================================================== */
+typedef struct {
+  int n_q, bins, dim, in_dim;
+  float* input_proj;  /* [dim][in_dim]  (conv1d k=1, no bias — :275-282) */
+  float* output_proj; /* [in_dim][dim] */
+  float* embedding;   /* [n_q][bins][dim] = embedding_sum / max(cluster_usage, eps) — :91-94 */
+  float* c2;          /* [n_q][bins] = sum(e*e)/2 — :95 */
+} orc_rvq;
+
+static orc_rvq* rvq_load(wsrc* s, const char* prefix, int n_q, int bins, int dim, int in_dim) {
+  orc_rvq* r = (orc_rvq*)xcalloc(1, sizeof *r);
+  r->n_q = n_q; r->bins = bins; r->dim = dim; r->in_dim = in_dim;
+  r->input_proj = w_get(s, (int64_t)dim * in_dim, "%s.input_proj.weight", prefix);
+  r->output_proj = w_get(s, (int64_t)in_dim * dim, "%s.output_proj.weight", prefix);
+  r->embedding = (float*)xmalloc(sizeof(float) * (size_t)n_q * bins * dim);
+  r->c2 = (float*)xmalloc(sizeof(float) * (size_t)n_q * bins);
+  for (int i = 0; i < n_q; ++i) {
+    float* usage = w_get(s, bins, "%s.vq.layers.%d._codebook.cluster_usage", prefix, i);
+    float* esum = w_get(s, (int64_t)bins * dim, "%s.vq.layers.%d._codebook.embedding_sum", prefix, i);
+    for (int j = 0; j < bins; ++j) {
+      float u = usage[j] > 1e-5f ? usage[j] : 1e-5f; /* cluster_usage.maximum(epsilon) */
+      float ss = 0.0f;
+      for (int dd = 0; dd < dim; ++dd) {
+        float e = esum[(size_t)j * dim + dd] / u;
+        r->embedding[((size_t)i * bins + j) * dim + dd] = e;
+        ss = ss + e * e;
+      }
+      r->c2[(size_t)i * bins + j] = ss / 2.0f;
+    }
+    free(usage);
+    free(esum);
+  }
+  return r;
+}
+static void rvq_free(orc_rvq* r) {
+  if (!r) return;
+  free(r->input_proj); free(r->output_proj); free(r->embedding); free(r->c2); free(r);
+}
+
+/* ResidualVectorQuantizer::encode — :307-310 + ResidualVectorQuantization::encode :219-229 +
+ * VectorQuantization::encode :182-185 + EuclideanCodebook::encode_slow :122-131.
+ * xs [rows][in_dim] (rows = B*T') -> codes[row*stride_codes + code_off + i] */
+static void rvq_encode(const orc_rvq* r, const float* xs, int rows, uint32_t* codes, int stride_codes, int code_off) {
+  const int dim = r->dim, bins = r->bins;
+  float* res = (float*)xmalloc(sizeof(float) * (size_t)rows * dim);
+  float* dots = (float*)xmalloc(sizeof(float) * (size_t)rows * bins);
+  orc_linear(res, dim, xs, r->in_dim, r->input_proj, r->in_dim, NULL, rows, dim, r->in_dim);
+  for (int i = 0; i < r->n_q; ++i) {
+    const float* E = r->embedding + (size_t)i * bins * dim;
+    orc_linear(dots, bins, res, dim, E, dim, NULL, rows, bins, dim); /* xs.matmul(embedding.t()) */
+    for (int m = 0; m < rows; ++m) {
+      int best = 0;
+      float bestv = r->c2[(size_t)i * bins] - dots[(size_t)m * bins]; /* c2.broadcast_sub(dot_prod) */
+      for (int j = 1; j < bins; ++j) {
+        float v = r->c2[(size_t)i * bins + j] - dots[(size_t)m * bins + j];
+        if (v < bestv) { /* argmin: first occurrence on ties */
+          bestv = v;
+          best = j;
+        }
+      }
+      codes[(size_t)m * stride_codes + code_off + i] = (uint32_t)best;
+      for (int dd = 0; dd < dim; ++dd) res[(size_t)m * dim + dd] = res[(size_t)m * dim + dd] - E[(size_t)best * dim + dd];
+    }
+  }
+  free(res);
+  free(dots);
+}
+
+/* ======================================================================================
+ * Mimi (encode side) — core/mimi.rs:96-206
+ * ====================================================================================== */
+typedef struct {
+  dsm_mimi_config cfg;
+  int B;
+  orc_seanet_enc* encoder;
+  orc_transformer* enc_tr;
+  orc_conv1d* downsample; /* ConvDownsample1d: k = 2*stride, replicate pad, no bias — core/conv.rs:520-533 */
+  orc_rvq *rvq_first, *rvq_rest;
+  /* debug taps of the last step */
+  float *dbg_seanet, *dbg_tr, *dbg_latent;
+  int dbg_T, dbg_Tl;
+} orc_mimi;
+
+static orc_mimi* mimi_load(wsrc* s, int B, const dsm_mimi_config* cfg) {
+  orc_mimi* m = (orc_mimi*)xcalloc(1, sizeof *m);
+  m->cfg = *cfg;
+  m->B = B;
+  m->encoder = seanet_enc_load(s, B, cfg);
+  m->enc_tr = transformer_load(s, B, &cfg->transformer, "encoder_transformer.transformer", 0);
+  {
+    int dim = cfg->dimension, st = cfg->downsample_stride;
+    float* w = w_get(s, (int64_t)dim * dim * 2 * st, "downsample.conv.conv.conv.weight");
+    m->downsample = orc_conv1d_new(B, dim, dim, 2 * st, st, 1, 1, w, NULL);
+    free(w);
+  }
+  m->rvq_first = rvq_load(s, "quantizer.rvq_first", 1, cfg->quantizer_bins, cfg->quantizer_dim, cfg->dimension);
+  m->rvq_rest = cfg->quantizer_n_q > 1
+                    ? rvq_load(s, "quantizer.rvq_rest", cfg->quantizer_n_q - 1, cfg->quantizer_bins, cfg->quantizer_dim, cfg->dimension)
+                    : NULL;
+  return m;
+}
+static void mimi_free(orc_mimi* m) {
+  if (!m) return;
+  seanet_enc_free(m->encoder);
+  transformer_free(m->enc_tr);
+  orc_conv1d_free(m->downsample);
+  rvq_free(m->rvq_first);
+  rvq_free(m->rvq_rest);
+  free(m->dbg_seanet); free(m->dbg_tr); free(m->dbg_latent);
+  free(m);
+}
+
+/* Mimi::encode_step — core/mimi.rs:195-206.  Returns frames produced; codes [B][n_q][T'] */
+static int mimi_encode_step(orc_mimi* m, const float* pcm, int T, const uint8_t* mask, uint32_t* codes) {
+  const int B = m->B, dim = m->cfg.dimension, n_q = m->cfg.quantizer_n_q;
+  float* xs = NULL;
+  int Te = seanet_enc_step(m->encoder, pcm, T, mask, &xs);
+  if (Te == 0) { free(xs); return 0; }
+  free(m->dbg_seanet);
+  m->dbg_seanet = (float*)xmalloc(sizeof(float) * (size_t)B * Te * dim);
+  memcpy(m->dbg_seanet, xs, sizeof(float) * (size_t)B * Te * dim);
+  m->dbg_T = Te;
+  /* ProjectedTransformer::step — core/batched_transformer.rs:584-602 (conv_layout transposes are
+   * the identity in channels-last storage; input_proj/output_proj absent since dims match) */
+  transformer_forward(m->enc_tr, xs, Te, mask);
+  free(m->dbg_tr);
+  m->dbg_tr = (float*)xmalloc(sizeof(float) * (size_t)B * Te * dim);
+  memcpy(m->dbg_tr, xs, sizeof(float) * (size_t)B * Te * dim);
+  int cap = Te / m->downsample->stride + 2;
+  float* lat = (float*)xmalloc(sizeof(float) * (size_t)B * cap * dim);
+  int Tl = orc_conv1d_step(m->downsample, xs, Te, mask, lat, cap);
+  free(xs);
+  if (Tl == 0) { free(lat); return 0; }
+  free(m->dbg_latent);
+  m->dbg_latent = (float*)xmalloc(sizeof(float) * (size_t)B * Tl * dim);
+  memcpy(m->dbg_latent, lat, sizeof(float) * (size_t)B * Tl * dim);
+  m->dbg_Tl = Tl;
+  /* SplitResidualVectorQuantizer::encode — core/quantization.rs:366-378: rvq_rest re-encodes xs itself */
+  uint32_t* tmp = (uint32_t*)xmalloc(sizeof(uint32_t) * (size_t)B * Tl * n_q);
+  rvq_encode(m->rvq_first, lat, B * Tl, tmp, n_q, 0);
+  if (m->rvq_rest) rvq_encode(m->rvq_rest, lat, B * Tl, tmp, n_q, 1);
+  for (int b = 0; b < B; ++b)
+    for (int t = 0; t < Tl; ++t)
+      for (int i = 0; i < n_q; ++i) codes[((size_t)b * n_q + i) * Tl + t] = tmp[((size_t)b * Tl + t) * n_q + i];
+  free(tmp);
+  free(lat);
+  return Tl;
+}
+
+/* Mimi::reset_batch_idx — core/mimi.rs:236-244 (encode-side members) */
+static void mimi_reset_batch_idx(orc_mimi* m, int b) {
+  orc_kvb_reset_batch_index(m->enc_tr->builder, b);
+  seanet_enc_reset_batch_idx(m->encoder, b);
+  orc_conv1d_reset_batch_idx(m->downsample, b);
+}
+
+/* ======================================================================================
+ * LmModel — core/lm.rs:796-1008
+ * ====================================================================================== */
+typedef struct {
+  dsm_asr_config cfg;
+  int B;
+  float* text_emb;    /* [text_in_vocab][d] */
+  float** audio_embs; /* audio_codebooks x [audio_vocab][d] */
+  orc_transformer* tr;
+  float* out_norm;
+  float* text_linear; /* [text_out_vocab][d] */
+  float* extra_heads; /* [n][dim][d] */
+  float *dbg_hidden, *dbg_logits;
+} orc_lm;
+
+static orc_lm* lm_load(wsrc* s, int B, const dsm_asr_config* cfg) {
+  orc_lm* m = (orc_lm*)xcalloc(1, sizeof *m);
+  m->cfg = *cfg;
+  m->B = B;
+  const int d = cfg->lm.d_model;
+  m->text_emb = w_get(s, (int64_t)cfg->text_in_vocab_size * d, "text_emb.weight");
+  m->audio_embs = (float**)xcalloc(cfg->audio_codebooks, sizeof(float*));
+  for (int i = 0; i < cfg->audio_codebooks; ++i) m->audio_embs[i] = w_get(s, (int64_t)cfg->audio_vocab_size * d, "emb.%d.weight", i);
+  m->tr = transformer_load(s, B, &cfg->lm, "transformer", cfg->kv_bf16);
+  m->out_norm = w_get(s, d, "out_norm.alpha");
+  m->text_linear = w_get(s, (int64_t)cfg->text_out_vocab_size * d, "text_linear.weight");
+  if (cfg->extra_heads_num > 0) {
+    m->extra_heads = (float*)xmalloc(sizeof(float) * (size_t)cfg->extra_heads_num * cfg->extra_heads_dim * d);
+    for (int i = 0; i < cfg->extra_heads_num; ++i) {
+      float* w = w_get(s, (int64_t)cfg->extra_heads_dim * d, "extra_heads.%d.weight", i);
+      memcpy(m->extra_heads + (size_t)i * cfg->extra_heads_dim * d, w, sizeof(float) * (size_t)cfg->extra_heads_dim * d);
+      free(w);
+    }
+  }
+  m->dbg_hidden = (float*)xcalloc((size_t)B * d, sizeof(float));
+  m->dbg_logits = (float*)xcalloc((size_t)B * cfg->text_out_vocab_size, sizeof(float));
+  return m;
+}
+static void lm_free(orc_lm* m) {
+  if (!m) return;
+  free(m->text_emb);
+  for (int i = 0; i < m->cfg.audio_codebooks; ++i) free(m->audio_embs[i]);
+  free(m->audio_embs);
+  transformer_free(m->tr);
+  free(m->out_norm); free(m->text_linear); free(m->extra_heads); free(m->dbg_hidden); free(m->dbg_logits);
+  free(m);
+}
+
+/* forward_cond (conditions = None) — core/lm.rs:957-1008, T = 1.
+ * text_ids [B], audio_ids [B][codebooks] -> logits [B][V] and ys (post out_norm) [B][d] */
+static void lm_forward(orc_lm* m, const uint32_t* text_ids, const uint32_t* audio_ids, const uint8_t* mask) {
+  const int B = m->B, d = m->cfg.lm.d_model, nc = m->cfg.audio_codebooks;
+  float* emb = (float*)xmalloc(sizeof(float) * (size_t)B * d);
+  for (int b = 0; b < B; ++b) {
+    const float* te = m->text_emb + (size_t)text_ids[b] * d;
+    for (int j = 0; j < d; ++j) emb[(size_t)b * d + j] = te[j];
+    for (int i = 0; i < nc; ++i) { /* emb = emb + e, in codebook order — :988-993 */
+      const float* ae = m->audio_embs[i] + (size_t)audio_ids[(size_t)b * nc + i] * d;
+      for (int j = 0; j < d; ++j) emb[(size_t)b * d + j] = emb[(size_t)b * d + j] + ae[j];
+    }
+  }
+  transformer_forward(m->tr, emb, 1, mask);
+  orc_rmsnorm(m->dbg_hidden, emb, m->out_norm, B, d, 1e-8f); /* out_norm — :1002 */
+  orc_linear(m->dbg_logits, m->cfg.text_out_vocab_size, m->dbg_hidden, d, m->text_linear, d, NULL, B,
+             m->cfg.text_out_vocab_size, d); /* :1003 */
+  free(emb);
+}
+
+/* ======================================================================================
+ * asr::State — core/asr.rs
+ * ====================================================================================== */
+typedef struct { /* ItemState — core/asr.rs:15-51 */
+  size_t step_idx;
+  uint32_t text_token;
+  uint32_t* word_tokens;
+  int n_word_tokens, cap_word_tokens;
+  int unended_word;
+  double last_stop_time;
+} orc_item;
+
+struct orc_asr {
+  dsm_asr_config cfg;
+  int B;
+  orc_lm* lm;
+  orc_mimi* mimi[2]; /* [0] encoder-thread clone (srv/batched_asr.rs:297), [1] state.audio_tokenizer */
+  orc_item* batch;
+  uint32_t* next_codebooks; /* [B][codebooks] — core/asr.rs:61 */
+  size_t model_step_idx;
+  /* message queue of the last step */
+  dsm_asr_msg* msgs;
+  int n_msgs, cap_msgs;
+  uint32_t* msg_tokens;
+  int n_msg_tokens, cap_msg_tokens;
+};
+
+static void push_msg(orc_asr* a, dsm_asr_msg m, const uint32_t* toks) {
+  if (a->n_msgs == a->cap_msgs) {
+    a->cap_msgs = a->cap_msgs ? 2 * a->cap_msgs : 64;
+    a->msgs = (dsm_asr_msg*)realloc(a->msgs, sizeof(dsm_asr_msg) * (size_t)a->cap_msgs);
+  }
+  if (m.kind == DSM_MSG_WORD) {
+    if (a->n_msg_tokens + m.n_tokens > a->cap_msg_tokens) {
+      a->cap_msg_tokens = 2 * (a->n_msg_tokens + m.n_tokens) + 64;
+      a->msg_tokens = (uint32_t*)realloc(a->msg_tokens, sizeof(uint32_t) * (size_t)a->cap_msg_tokens);
+    }
+    m.tokens_offset = a->n_msg_tokens;
+    memcpy(a->msg_tokens + a->n_msg_tokens, toks, sizeof(uint32_t) * (size_t)m.n_tokens);
+    a->n_msg_tokens += m.n_tokens;
+  }
+  a->msgs[a->n_msgs++] = m;
+}
+
+orc_asr* orc_asr_create(const dsm_asr_config* cfg, int batch_size, const char* lm_path, const char* mimi_path,
+                        char* err, size_t errcap) {
+  if (cfg->temperature > 0.0f) {
+    snprintf(err, errcap, "temperature > 0 (gumbel_softmax, core/asr.rs:211-215) is outside the hot path");
+    return NULL;
+  }
+  wsrc sl = {dsm_st_open(lm_path, err, errcap), err, errcap, 0};
+  if (!sl.f) return NULL;
+  wsrc sm = {dsm_st_open(mimi_path, err, errcap), err, errcap, 0};
+  if (!sm.f) {
+    dsm_st_close(sl.f);
+    return NULL;
+  }
+  orc_asr* a = (orc_asr*)xcalloc(1, sizeof *a);
+  a->cfg = *cfg;
+  a->B = batch_size;
+  a->lm = lm_load(&sl, batch_size, cfg);
+  a->mimi[0] = mimi_load(&sm, batch_size, &cfg->mimi);
+  a->mimi[1] = mimi_load(&sm, batch_size, &cfg->mimi);
+  int failed = sl.failed || sm.failed;
+  dsm_st_close(sl.f);
+  dsm_st_close(sm.f);
+  if (failed) {
+    orc_asr_destroy(a);
+    return NULL;
+  }
+  /* State::new — core/asr.rs:65-88 */
+  a->batch = (orc_item*)xcalloc(batch_size, sizeof(orc_item));
+  for (int b = 0; b < batch_size; ++b) a->batch[b].text_token = (uint32_t)cfg->text_in_vocab_size - 1; /* text_start_token */
+  a->next_codebooks = (uint32_t*)xmalloc(sizeof(uint32_t) * (size_t)batch_size * cfg->audio_codebooks);
+  for (int i = 0; i < batch_size * cfg->audio_codebooks; ++i) a->next_codebooks[i] = (uint32_t)cfg->audio_vocab_size - 1; /* audio_pad_token */
+  return a;
+}
+
+void orc_asr_destroy(orc_asr* a) {
+  if (!a) return;
+  lm_free(a->lm);
+  mimi_free(a->mimi[0]);
+  mimi_free(a->mimi[1]);
+  if (a->batch)
+    for (int b = 0; b < a->B; ++b) free(a->batch[b].word_tokens);
+  free(a->batch); free(a->next_codebooks); free(a->msgs); free(a->msg_tokens);
+  free(a);
+}
+
+int orc_mimi_encode_step(orc_asr* a, int side, const float* pcm, const uint8_t* mask, uint32_t* codes_out) {
+  return mimi_encode_step(a->mimi[side ? 1 : 0], pcm, DSM_FRAME_SIZE, mask, codes_out);
+}
+
+/* State::step_tokens — core/asr.rs:147-255 (steps == 1: codes [B][codebooks][1]) */
+int orc_asr_step_tokens(orc_asr* a, const uint32_t* codes, const uint8_t* mask, uint32_t* text_tokens_out,
+                        float* vad_prs_out) {
+  const int B = a->B, nc = a->cfg.audio_codebooks, d = a->cfg.lm.d_model;
+  const uint32_t pad = (uint32_t)a->cfg.audio_vocab_size - 1, start = (uint32_t)a->cfg.text_in_vocab_size - 1;
+  a->n_msgs = 0;
+  a->n_msg_tokens = 0;
+  uint32_t* next_tokens = (uint32_t*)xmalloc(sizeof(uint32_t) * (size_t)B * nc);
+  uint32_t* text = (uint32_t*)xmalloc(sizeof(uint32_t) * (size_t)B);
+  for (int b = 0; b < B; ++b) {
+    int first = a->batch[b].step_idx == 0; /* is_first_step — :165-166 */
+    for (int i = 0; i < nc; ++i) next_tokens[(size_t)b * nc + i] = first ? pad : a->next_codebooks[(size_t)b * nc + i]; /* :172-175 */
+    if (mask[b]) memcpy(a->next_codebooks + (size_t)b * nc, codes + (size_t)b * nc, sizeof(uint32_t) * nc); /* :177-183 */
+    text[b] = first ? start : a->batch[b].text_token; /* text_tokens() — :133-145 */
+  }
+  lm_forward(a->lm, text, next_tokens, mask); /* :191-192 */
+  a->model_step_idx += 1;
+  /* extra heads: softmax over the last dim in f32, class 0 — :195-206 */
+  const int nh = a->cfg.extra_heads_num, hdim = a->cfg.extra_heads_dim;
+  if (nh > 0) {
+    float* eh = (float*)xmalloc(sizeof(float) * (size_t)B * nh * hdim);
+    orc_linear(eh, nh * hdim, a->lm->dbg_hidden, d, a->lm->extra_heads, d, NULL, B, nh * hdim, d);
+    for (int h = 0; h < nh; ++h)
+      for (int b = 0; b < B; ++b) {
+        const float* lg = eh + ((size_t)b * nh + h) * hdim;
+        float m = lg[0];
+        for (int i = 1; i < hdim; ++i) m = lg[i] > m ? lg[i] : m;
+        float sum = 0.0f, e0 = 0.0f;
+        for (int i = 0; i < hdim; ++i) {
+          float e = dsm_expf(lg[i] - m);
+          if (i == 0) e0 = e;
+          sum = sum + e;
+        }
+        if (vad_prs_out) vad_prs_out[(size_t)h * B + b] = e0 / sum;
+      }
+    free(eh);
+    dsm_asr_msg m;
+    memset(&m, 0, sizeof m);
+    m.kind = DSM_MSG_STEP;
+    m.step_idx = (int)a->model_step_idx;
+    push_msg(a, m, NULL);
+  }
+  /* argmax (temperature <= 0) — :208-217 */
+  const int V = a->cfg.text_out_vocab_size;
+  for (int b = 0; b < B; ++b) {
+    const float* lg = a->lm->dbg_logits + (size_t)b * V;
+    int best = 0;
+    for (int j = 1; j < V; ++j)
+      if (lg[j] > lg[best]) best = j;
+    uint32_t text_token = (uint32_t)best;
+    text_tokens_out[b] = text_token;
+    if (!mask[b]) continue; /* :221-223 */
+    orc_item* it = &a->batch[b];
+    it->text_token = text_token;
+    it->step_idx += 1;
+    if (it->step_idx >= (size_t)a->cfg.asr_delay_in_tokens) { /* :228-251 */
+      if (text_token == 3 || text_token == 0) {
+        if (it->n_word_tokens > 0) {
+          dsm_asr_msg m;
+          memset(&m, 0, sizeof m);
+          m.kind = DSM_MSG_WORD;
+          m.batch_idx = b;
+          m.time = it->last_stop_time;
+          m.n_tokens = it->n_word_tokens;
+          push_msg(a, m, it->word_tokens);
+          it->n_word_tokens = 0;
+          it->unended_word = 1;
+        }
+      } else {
+        if (it->n_word_tokens == it->cap_word_tokens) {
+          it->cap_word_tokens = it->cap_word_tokens ? 2 * it->cap_word_tokens : 16;
+          it->word_tokens = (uint32_t*)realloc(it->word_tokens, sizeof(uint32_t) * (size_t)it->cap_word_tokens);
+        }
+        it->word_tokens[it->n_word_tokens++] = text_token;
+      }
+      if (text_token == 0) {
+        double stop_time = (double)(it->step_idx - (size_t)a->cfg.asr_delay_in_tokens) / 12.5;
+        if (it->unended_word) {
+          it->unended_word = 0;
+          dsm_asr_msg m;
+          memset(&m, 0, sizeof m);
+          m.kind = DSM_MSG_END_WORD;
+          m.batch_idx = b;
+          m.time = stop_time;
+          push_msg(a, m, NULL);
+        }
+        it->last_stop_time = stop_time;
+      }
+    }
+  }
+  free(next_tokens);
+  free(text);
+  return 0;
+}
+
+/* State::reset_batch_idx — core/asr.rs:257-266 */
+int orc_asr_reset_slot(orc_asr* a, int slot) {
+  if (slot < 0 || slot >= a->B) return DSM_ERR_INVALID;
+  orc_item* it = &a->batch[slot];
+  it->step_idx = 0;
+  it->text_token = (uint32_t)a->cfg.text_in_vocab_size - 1;
+  it->n_word_tokens = 0;
+  it->unended_word = 0;
+  it->last_stop_time = 0.0;
+  orc_kvb_reset_batch_index(a->lm->tr->builder, slot); /* LmModel::reset_batch_idx — core/lm.rs:1108 */
+  mimi_reset_batch_idx(a->mimi[1], slot);               /* self.audio_tokenizer.reset_batch_idx */
+  return 0;
+}
+
+int orc_mimi_reset_slot(orc_asr* a, int side, int slot) {
+  if (slot < 0 || slot >= a->B) return DSM_ERR_INVALID;
+  mimi_reset_batch_idx(a->mimi[side ? 1 : 0], slot);
+  return 0;
+}
+
+int orc_asr_poll_msgs(orc_asr* a, dsm_asr_msg* msgs, int cap, uint32_t* tokens_out, int tokens_cap) {
+  int n = MINI(cap, a->n_msgs);
+  for (int i = 0; i < n; ++i) msgs[i] = a->msgs[i];
+  int nt = MINI(tokens_cap, a->n_msg_tokens);
+  if (tokens_out && nt > 0) memcpy(tokens_out, a->msg_tokens, sizeof(uint32_t) * (size_t)nt);
+  return n;
+}
+
+int orc_debug_read(orc_asr* a, const char* name, float* out, size_t cap) {
+  const float* src = NULL;
+  size_t n = 0;
+  const int B = a->B;
+  orc_mimi* m = a->mimi[0];
+  if (!strncmp(name, "mimi1.", 6)) {
+    m = a->mimi[1];
+    name += 6;
+  } else if (!strncmp(name, "mimi.", 5)) {
+    name += 5;
+  }
+  if (!strcmp(name, "lm.hidden")) { src = a->lm->dbg_hidden; n = (size_t)B * a->cfg.lm.d_model; }
+  else if (!strcmp(name, "lm.logits")) { src = a->lm->dbg_logits; n = (size_t)B * a->cfg.text_out_vocab_size; }
+  else if (!strcmp(name, "seanet_out")) { src = m->dbg_seanet; n = (size_t)B * m->dbg_T * m->cfg.dimension; }
+  else if (!strcmp(name, "transformer_out")) { src = m->dbg_tr; n = (size_t)B * m->dbg_T * m->cfg.dimension; }
+  else if (!strcmp(name, "latent")) { src = m->dbg_latent; n = (size_t)B * m->dbg_Tl * m->cfg.dimension; }
+  if (!src) return -1;
+  if (n > cap) n = cap;
+  memcpy(out, src, sizeof(float) * n);
+  return (int)n;
+}
