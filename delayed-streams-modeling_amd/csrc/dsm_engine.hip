@@ -1,0 +1,611 @@
+// dsm_engine.hip — libdsm_mi355x.so: the engine behind include/dsm.h.
+//
+// Host orchestration of the per-80 ms-frame batched step on one MI355X:
+//   encoder side  (HIP stream "enc")   Mimi::encode_step      core/mimi.rs:195-206
+//   model side    (HIP stream "model") asr::State::step_tokens core/asr.rs:147-255
+// All per-slot state (conv carries, ring KV caches, ring index/position, item state) lives in
+// HBM and is advanced by the kernels themselves; the only per-step host<->device traffic is the
+// PCM/mask upload and the token/VAD download, like the reference (SURVEY.md §2.1 last paragraph).
+// There is no CPU fallback: creation fails if no HIP device is usable.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/dsm.h"
+#include "dsm_config_presets.h"
+#include "dsm_kernels.h"
+#include "dsm_numerics.h"
+#include "dsm_safetensors.h"
+
+static thread_local std::string g_create_error;
+
+#define HIPCHK_E(eng, expr)                                                                         \
+  do {                                                                                              \
+    hipError_t _e = (expr);                                                                         \
+    if (_e != hipSuccess) {                                                                         \
+      (eng)->set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);  \
+      return DSM_ERR_DEVICE;                                                                        \
+    }                                                                                               \
+  } while (0)
+#define HIPCHK(expr) HIPCHK_E(e, expr)
+
+namespace {
+
+struct Linear {  // packed weight [Npad][Kpad] (+ optional bias) on the device
+  void* w = nullptr;
+  float* bias = nullptr;
+  int N = 0, K = 0, Npad = 0, Kpad = 0;
+  bool bf16 = false;
+};
+
+struct ConvGeom {
+  Linear lin;
+  int in_c = 0, out_c = 0, k = 0, stride = 1;
+  int S = 0;     // carried frames = k_eff - stride (dilation 1)
+  int T_in = 0;  // input frames per step
+  int T_out = 0;
+  bool replicate = false;
+};
+
+struct TLayerW {
+  Linear in_proj, out_proj, ff_in, ff_out;
+  float *n1w = nullptr, *n1b = nullptr, *n2w = nullptr, *n2b = nullptr, *ls1 = nullptr, *ls2 = nullptr;
+};
+
+struct TransformerW {
+  dsm_transformer_config cfg{};
+  int hidden = 0;
+  std::vector<TLayerW> layers;
+  float* inv_freq = nullptr;
+};
+
+struct TransformerState {  // per (side): ring caches + ScatteredCacheBuilder state
+  std::vector<void*> k, v;  // per layer [B][H][ctx][hd]
+  uint32_t *pos = nullptr, *idx = nullptr, *start_pos = nullptr, *widx = nullptr;
+  float* rope_cs = nullptr;
+};
+
+struct RvqW {
+  Linear input_proj;
+  int n_q = 0;
+  std::vector<Linear> codebooks;  // W = embedding [bins][dim] f32, bias = c2 [bins]
+};
+
+struct MimiW {
+  dsm_mimi_config cfg{};
+  ConvGeom init_conv, final_conv, downsample;
+  struct Stage {
+    ConvGeom ra, rb, down;
+  };
+  std::vector<Stage> stages;
+  TransformerW tr;
+  RvqW rvq_first, rvq_rest;
+};
+
+struct MimiState {  // one per side (encoder-thread clone / model side)
+  float* pcm = nullptr;  // == cat_init + S0 (the PCM frame is uploaded straight into the concat buffer)
+  float* cat_init = nullptr;
+  struct Stage {
+    float *y = nullptr, *cat_ra = nullptr, *cat_rb = nullptr, *cat_down = nullptr;
+  };
+  std::vector<Stage> stages;
+  float* cat_final = nullptr;
+  float *x_tr = nullptr, *xn = nullptr, *q = nullptr, *att = nullptr, *ff = nullptr;
+  float* cat_ds = nullptr;
+  float* latent = nullptr;
+  float *res_first = nullptr, *res_rest = nullptr, *pval = nullptr;
+  uint32_t* pidx = nullptr;
+  uint32_t* codes = nullptr;  // [B][n_q]
+  TransformerState tr;
+  ConvStateDesc* descs = nullptr;  // device table for the state-shift kernel
+  std::vector<ConvStateDesc> h_descs;
+  int ds_desc = -1;  // index of the downsample conv in descs
+  bool first_call = true;
+  uint8_t* mask = nullptr;  // device [B]
+};
+
+struct LmW {
+  uint16_t* text_emb = nullptr;
+  uint16_t* audio_emb = nullptr;
+  TransformerW tr;
+  float* out_norm = nullptr;
+  Linear text_linear, extra_heads;
+};
+
+struct LmState {
+  float *x = nullptr, *xn = nullptr, *q = nullptr, *att = nullptr, *g = nullptr, *hidden = nullptr, *logits = nullptr,
+        *eh = nullptr, *prs = nullptr;
+  uint32_t *next_cb = nullptr, *text_token = nullptr, *text_out = nullptr, *codes_in = nullptr;
+  uint8_t *first_step = nullptr, *mask = nullptr;
+  TransformerState tr;
+};
+
+struct HostItem {  // ItemState — core/asr.rs:15-51 (word assembly stays on the host)
+  size_t step_idx = 0;
+  std::vector<uint32_t> word_tokens;
+  bool unended_word = false;
+  double last_stop_time = 0.0;
+};
+
+}  // namespace
+
+struct dsm_engine {
+  dsm_asr_config cfg{};
+  int B = 0, device = 0;
+  hipStream_t s_enc = nullptr, s_model = nullptr;
+  hipEvent_t ev_join = nullptr, ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;
+  MimiW mimi_w;
+  MimiState mimi[2];
+  LmW lm_w;
+  LmState lm;
+  std::vector<void*> allocs;
+  std::string err;
+  // host staging (pinned)
+  float* h_pcm = nullptr;
+  uint8_t* h_mask = nullptr;
+  uint32_t *h_codes = nullptr, *h_text = nullptr;
+  float* h_prs = nullptr;
+  // host item state + message queue
+  std::vector<HostItem> items;
+  size_t model_step_idx = 0;
+  std::vector<dsm_asr_msg> msgs;
+  std::vector<uint32_t> msg_tokens;
+  dsm_metrics metrics{};
+
+  void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    err = buf;
+  }
+
+  template <typename T>
+  int dalloc(T** out, size_t count, bool zero = true) {
+    void* p = nullptr;
+    size_t bytes = count * sizeof(T) + 256;  // slack: K-padding reads of the GEMM may run past a row
+    HIPCHK_E(this, hipMalloc(&p, bytes));
+    if (zero) HIPCHK_E(this, hipMemset(p, 0, bytes));
+    allocs.push_back(p);
+    *out = reinterpret_cast<T*>(p);
+    return 0;
+  }
+  template <typename T>
+  int upload(T** out, const T* host, size_t count) {
+    if (int rc = dalloc(out, count)) return rc;
+    HIPCHK_E(this, hipMemcpy(*out, host, count * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+  }
+};
+
+// ----------------------------------------------------------------------------------------------
+// weight loading
+// ----------------------------------------------------------------------------------------------
+namespace {
+
+struct Loader {
+  dsm_engine* e;
+  dsm_st_file* f;
+  bool failed = false;
+  std::vector<float> get(int64_t numel, const char* fmt, ...) __attribute__((format(printf, 3, 4))) {
+    char name[256];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(name, sizeof name, fmt, ap);
+    va_end(ap);
+    std::vector<float> out((size_t)numel);
+    if (failed) return out;
+    char err[512];
+    if (dsm_st_read_f32(f, name, numel, out.data(), err, sizeof err)) {
+      e->set_error("%s", err);
+      failed = true;
+    }
+    return out;
+  }
+  bool has(const char* fmt, ...) __attribute__((format(printf, 2, 3))) {
+    char name[256];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(name, sizeof name, fmt, ap);
+    va_end(ap);
+    return dsm_st_find(f, name) != nullptr;
+  }
+};
+
+int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// pack [N][K] f32 row-major into the GEMM layout [Npad][Kpad] (zero padded)
+int pack_linear(dsm_engine* e, Linear* L, const float* w, int N, int K, bool bf16, const float* bias) {
+  L->N = N;
+  L->K = K;
+  L->Npad = round_up(N, 32);
+  L->Kpad = round_up(K, 32);
+  L->bf16 = bf16;
+  size_t n = (size_t)L->Npad * L->Kpad;
+  if (bf16) {
+    std::vector<uint16_t> p(n, 0);
+    for (int i = 0; i < N; ++i)
+      for (int j = 0; j < K; ++j) p[(size_t)i * L->Kpad + j] = dsm_f32_to_bf16(w[(size_t)i * K + j]);
+    uint16_t* d = nullptr;
+    if (int rc = e->upload(&d, p.data(), n)) return rc;
+    L->w = d;
+  } else {
+    std::vector<float> p(n, 0.0f);
+    for (int i = 0; i < N; ++i) memcpy(&p[(size_t)i * L->Kpad], &w[(size_t)i * K], sizeof(float) * K);
+    float* d = nullptr;
+    if (int rc = e->upload(&d, p.data(), n)) return rc;
+    L->w = d;
+  }
+  if (bias) {
+    std::vector<float> pb((size_t)L->Npad, 0.0f);
+    memcpy(pb.data(), bias, sizeof(float) * N);
+    if (int rc = e->upload(&L->bias, pb.data(), pb.size())) return rc;
+  }
+  return 0;
+}
+
+// conv1d_weight_norm — core/conv.rs:27-45
+std::vector<float> load_conv_weight(Loader& ld, const char* prefix, int out_c, int in_c, int k) {
+  if (ld.has("%s.weight", prefix)) return ld.get((int64_t)out_c * in_c * k, "%s.weight", prefix);
+  std::vector<float> g = ld.get(out_c, "%s.weight_g", prefix);
+  std::vector<float> v = ld.get((int64_t)out_c * in_c * k, "%s.weight_v", prefix);
+  for (int o = 0; o < out_c; ++o) {
+    float ss = 0.0f;
+    for (int i = 0; i < in_c * k; ++i) ss = ss + v[(size_t)o * in_c * k + i] * v[(size_t)o * in_c * k + i];
+    float nrm = sqrtf(ss);
+    for (int i = 0; i < in_c * k; ++i) v[(size_t)o * in_c * k + i] = v[(size_t)o * in_c * k + i] * g[o] / nrm;
+  }
+  return v;
+}
+
+int load_conv(dsm_engine* e, Loader& ld, ConvGeom* c, const char* prefix, int in_c, int out_c, int k, int stride,
+              bool bias, bool replicate, const char* wkey = nullptr) {
+  char p[256];
+  if (wkey)
+    snprintf(p, sizeof p, "%s", wkey);
+  else
+    snprintf(p, sizeof p, "%s.conv.conv", prefix);
+  std::vector<float> w = load_conv_weight(ld, p, out_c, in_c, k);
+  std::vector<float> b;
+  if (bias) b = ld.get(out_c, "%s.bias", p);
+  if (ld.failed) return DSM_ERR_IO;
+  // [out_c][in_c][k] -> [out_c][k*in_c] (kk-major reduction index)
+  std::vector<float> r((size_t)out_c * k * in_c);
+  for (int o = 0; o < out_c; ++o)
+    for (int ci = 0; ci < in_c; ++ci)
+      for (int kk = 0; kk < k; ++kk) r[((size_t)o * k + kk) * in_c + ci] = w[((size_t)o * in_c + ci) * k + kk];
+  c->in_c = in_c;
+  c->out_c = out_c;
+  c->k = k;
+  c->stride = stride;
+  c->S = k - stride;
+  c->replicate = replicate;
+  return pack_linear(e, &c->lin, r.data(), out_c, k * in_c, false, bias ? b.data() : nullptr);
+}
+
+int gating_hidden(const dsm_transformer_config& c) {  // core/batched_transformer.rs:153-157
+  return c.dim_feedforward == 4 * c.d_model ? 11 * c.d_model / 4 : 2 * c.dim_feedforward / 3;
+}
+
+int load_transformer(dsm_engine* e, Loader& ld, TransformerW* t, const dsm_transformer_config& cfg,
+                     const char* prefix, bool bf16) {
+  t->cfg = cfg;
+  const int d = cfg.d_model, hd = d / cfg.num_heads;
+  t->hidden = cfg.gating ? gating_hidden(cfg) : cfg.dim_feedforward;
+  t->layers.resize(cfg.num_layers);
+  std::vector<float> inv(hd / 2);
+  for (int i = 0; i < hd / 2; ++i)  // RotaryEmbedding::new — core/transformer.rs:386-392
+    inv[i] = (float)(1.0 / pow((double)cfg.max_period, (double)(2 * i) / (double)hd));
+  if (int rc = e->upload(&t->inv_freq, inv.data(), inv.size())) return rc;
+  for (int l = 0; l < cfg.num_layers; ++l) {
+    TLayerW& L = t->layers[l];
+    {
+      auto w = ld.get((int64_t)3 * d * d, "%s.layers.%d.self_attn.in_proj_weight", prefix, l);
+      if (ld.failed) return DSM_ERR_IO;
+      if (int rc = pack_linear(e, &L.in_proj, w.data(), 3 * d, d, bf16, nullptr)) return rc;
+    }
+    {
+      auto w = ld.get((int64_t)d * d, "%s.layers.%d.self_attn.out_proj.weight", prefix, l);
+      if (ld.failed) return DSM_ERR_IO;
+      if (int rc = pack_linear(e, &L.out_proj, w.data(), d, d, bf16, nullptr)) return rc;
+    }
+    for (int which = 1; which <= 2; ++which) {
+      float** w = which == 1 ? &L.n1w : &L.n2w;
+      float** b = which == 1 ? &L.n1b : &L.n2b;
+      std::vector<float> wv, bv;
+      if (cfg.norm == 1) {
+        wv = ld.get(d, "%s.layers.%d.norm%d.alpha", prefix, l, which);
+      } else {
+        bv = ld.get(d, "%s.layers.%d.norm%d.bias", prefix, l, which);
+        if (ld.has("%s.layers.%d.norm%d.alpha", prefix, l, which))
+          wv = ld.get(d, "%s.layers.%d.norm%d.alpha", prefix, l, which);
+        else
+          wv = ld.get(d, "%s.layers.%d.norm%d.weight", prefix, l, which);
+      }
+      if (ld.failed) return DSM_ERR_IO;
+      if (int rc = e->upload(w, wv.data(), wv.size())) return rc;
+      if (!bv.empty())
+        if (int rc = e->upload(b, bv.data(), bv.size())) return rc;
+    }
+    if (cfg.gating) {
+      auto wi = ld.get((int64_t)2 * t->hidden * d, "%s.layers.%d.gating.linear_in.weight", prefix, l);
+      if (ld.failed) return DSM_ERR_IO;
+      if (int rc = pack_linear(e, &L.ff_in, wi.data(), 2 * t->hidden, d, bf16, nullptr)) return rc;
+      auto wo = ld.get((int64_t)d * t->hidden, "%s.layers.%d.gating.linear_out.weight", prefix, l);
+      if (ld.failed) return DSM_ERR_IO;
+      if (int rc = pack_linear(e, &L.ff_out, wo.data(), d, t->hidden, bf16, nullptr)) return rc;
+    } else {
+      auto wi = ld.get((int64_t)t->hidden * d, "%s.layers.%d.linear1.weight", prefix, l);
+      if (ld.failed) return DSM_ERR_IO;
+      if (int rc = pack_linear(e, &L.ff_in, wi.data(), t->hidden, d, bf16, nullptr)) return rc;
+      auto wo = ld.get((int64_t)d * t->hidden, "%s.layers.%d.linear2.weight", prefix, l);
+      if (ld.failed) return DSM_ERR_IO;
+      if (int rc = pack_linear(e, &L.ff_out, wo.data(), d, t->hidden, bf16, nullptr)) return rc;
+    }
+    if (cfg.layer_scale) {
+      auto s1 = ld.get(d, "%s.layers.%d.layer_scale_1.scale", prefix, l);
+      auto s2 = ld.get(d, "%s.layers.%d.layer_scale_2.scale", prefix, l);
+      if (ld.failed) return DSM_ERR_IO;
+      if (int rc = e->upload(&L.ls1, s1.data(), s1.size())) return rc;
+      if (int rc = e->upload(&L.ls2, s2.data(), s2.size())) return rc;
+    }
+  }
+  return 0;
+}
+
+int alloc_transformer_state(dsm_engine* e, TransformerState* st, const dsm_transformer_config& cfg, int B, int T,
+                            bool kv_bf16) {
+  const int H = cfg.num_heads, hd = cfg.d_model / H;
+  size_t per = (size_t)B * H * cfg.context * hd;
+  st->k.resize(cfg.num_layers);
+  st->v.resize(cfg.num_layers);
+  for (int l = 0; l < cfg.num_layers; ++l) {
+    if (kv_bf16) {
+      uint16_t *k = nullptr, *v = nullptr;
+      if (int rc = e->dalloc(&k, per)) return rc;
+      if (int rc = e->dalloc(&v, per)) return rc;
+      st->k[l] = k;
+      st->v[l] = v;
+    } else {
+      float *k = nullptr, *v = nullptr;
+      if (int rc = e->dalloc(&k, per)) return rc;
+      if (int rc = e->dalloc(&v, per)) return rc;
+      st->k[l] = k;
+      st->v[l] = v;
+    }
+  }
+  if (int rc = e->dalloc(&st->pos, B)) return rc;
+  if (int rc = e->dalloc(&st->idx, B)) return rc;
+  if (int rc = e->dalloc(&st->start_pos, B)) return rc;
+  if (int rc = e->dalloc(&st->widx, (size_t)B * T)) return rc;
+  if (int rc = e->dalloc(&st->rope_cs, (size_t)B * T * hd)) return rc;
+  return 0;
+}
+
+int load_rvq(dsm_engine* e, Loader& ld, RvqW* r, const char* prefix, int n_q, const dsm_mimi_config& m) {
+  const int bins = m.quantizer_bins, dim = m.quantizer_dim;
+  r->n_q = n_q;
+  auto ip = ld.get((int64_t)dim * m.dimension, "%s.input_proj.weight", prefix);
+  if (ld.failed) return DSM_ERR_IO;
+  if (int rc = pack_linear(e, &r->input_proj, ip.data(), dim, m.dimension, false, nullptr)) return rc;
+  r->codebooks.resize(n_q);
+  for (int i = 0; i < n_q; ++i) {
+    auto usage = ld.get(bins, "%s.vq.layers.%d._codebook.cluster_usage", prefix, i);
+    auto esum = ld.get((int64_t)bins * dim, "%s.vq.layers.%d._codebook.embedding_sum", prefix, i);
+    if (ld.failed) return DSM_ERR_IO;
+    std::vector<float> c2(bins);
+    for (int j = 0; j < bins; ++j) {  // EuclideanCodebook::new — core/quantization.rs:86-95
+      float u = usage[j] > 1e-5f ? usage[j] : 1e-5f;
+      float ss = 0.0f;
+      for (int dd = 0; dd < dim; ++dd) {
+        float v = esum[(size_t)j * dim + dd] / u;
+        esum[(size_t)j * dim + dd] = v;
+        ss = ss + v * v;
+      }
+      c2[j] = ss / 2.0f;
+    }
+    if (int rc = pack_linear(e, &r->codebooks[i], esum.data(), bins, dim, false, c2.data())) return rc;
+  }
+  return 0;
+}
+
+int load_mimi(dsm_engine* e, Loader& ld, MimiW* m, const dsm_mimi_config& cfg) {
+  m->cfg = cfg;
+  char p[128];
+  int mult = 1, idx = 0, T = DSM_FRAME_SIZE;
+  snprintf(p, sizeof p, "encoder.model.%d", idx);
+  if (int rc = load_conv(e, ld, &m->init_conv, p, cfg.channels, mult * cfg.n_filters, cfg.kernel_size, 1, true, false)) return rc;
+  m->init_conv.T_in = T;
+  m->init_conv.T_out = T;
+  idx += 1;
+  m->stages.resize(cfg.n_ratios);
+  for (int i = 0; i < cfg.n_ratios; ++i) {
+    int ratio = cfg.ratios[cfg.n_ratios - 1 - i];  // core/seanet.rs:194 ratios.iter().rev()
+    int dim = mult * cfg.n_filters, hidden = dim / cfg.compress;
+    MimiW::Stage& st = m->stages[i];
+    snprintf(p, sizeof p, "encoder.model.%d.block.1", idx);
+    if (int rc = load_conv(e, ld, &st.ra, p, dim, hidden, cfg.residual_kernel_size, 1, true, false)) return rc;
+    snprintf(p, sizeof p, "encoder.model.%d.block.3", idx);
+    if (int rc = load_conv(e, ld, &st.rb, p, hidden, dim, 1, 1, true, false)) return rc;
+    idx += 1;
+    snprintf(p, sizeof p, "encoder.model.%d", idx + 1);
+    if (int rc = load_conv(e, ld, &st.down, p, dim, dim * 2, ratio * 2, ratio, true, false)) return rc;
+    idx += 2;
+    st.ra.T_in = st.ra.T_out = st.rb.T_in = st.rb.T_out = st.down.T_in = T;
+    if (T % ratio) {
+      e->set_error("frame of %d samples does not divide by the encoder ratios", DSM_FRAME_SIZE);
+      return DSM_ERR_INVALID;
+    }
+    T /= ratio;
+    st.down.T_out = T;
+    mult *= 2;
+  }
+  snprintf(p, sizeof p, "encoder.model.%d", idx + 1);
+  if (int rc = load_conv(e, ld, &m->final_conv, p, mult * cfg.n_filters, cfg.dimension, cfg.last_kernel_size, 1, true, false)) return rc;
+  m->final_conv.T_in = m->final_conv.T_out = T;
+  if (int rc = load_transformer(e, ld, &m->tr, cfg.transformer, "encoder_transformer.transformer", false)) return rc;
+  if (int rc = load_conv(e, ld, &m->downsample, nullptr, cfg.dimension, cfg.dimension, 2 * cfg.downsample_stride,
+                         cfg.downsample_stride, false, true, "downsample.conv.conv.conv"))
+    return rc;
+  m->downsample.T_in = T;
+  if (T % cfg.downsample_stride) {
+    e->set_error("encoder frames per step (%d) do not divide by the downsample stride", T);
+    return DSM_ERR_INVALID;
+  }
+  m->downsample.T_out = T / cfg.downsample_stride;
+  if (m->downsample.T_out != 1) {
+    e->set_error("expected exactly one latent frame per step, got %d", m->downsample.T_out);
+    return DSM_ERR_INVALID;
+  }
+  if (int rc = load_rvq(e, ld, &m->rvq_first, "quantizer.rvq_first", 1, cfg)) return rc;
+  if (cfg.quantizer_n_q > 1)
+    if (int rc = load_rvq(e, ld, &m->rvq_rest, "quantizer.rvq_rest", cfg.quantizer_n_q - 1, cfg)) return rc;
+  return 0;
+}
+
+int alloc_cat(dsm_engine* e, float** out, const ConvGeom& c, int B) {
+  return e->dalloc(out, (size_t)B * (c.S + c.T_in) * c.in_c);
+}
+
+void add_desc(MimiState* s, float* cat, const ConvGeom& c) {
+  if (c.S == 0) return;
+  ConvStateDesc d;
+  d.cat = cat;
+  d.bstride = (long)(c.S + c.T_in) * c.in_c;
+  d.S = c.S;
+  d.T = c.T_in;
+  d.C = c.in_c;
+  d.replicate = c.replicate ? 1 : 0;
+  s->h_descs.push_back(d);
+}
+
+int alloc_mimi_state(dsm_engine* e, MimiState* s, const MimiW& w, int B) {
+  const dsm_mimi_config& cfg = w.cfg;
+  if (int rc = alloc_cat(e, &s->cat_init, w.init_conv, B)) return rc;
+  add_desc(s, s->cat_init, w.init_conv);
+  s->stages.resize(w.stages.size());
+  for (size_t i = 0; i < w.stages.size(); ++i) {
+    const MimiW::Stage& st = w.stages[i];
+    if (int rc = e->dalloc(&s->stages[i].y, (size_t)B * st.ra.T_in * st.ra.in_c)) return rc;
+    if (int rc = alloc_cat(e, &s->stages[i].cat_ra, st.ra, B)) return rc;
+    if (int rc = alloc_cat(e, &s->stages[i].cat_rb, st.rb, B)) return rc;
+    if (int rc = alloc_cat(e, &s->stages[i].cat_down, st.down, B)) return rc;
+    add_desc(s, s->stages[i].cat_ra, st.ra);
+    add_desc(s, s->stages[i].cat_rb, st.rb);
+    add_desc(s, s->stages[i].cat_down, st.down);
+  }
+  if (int rc = alloc_cat(e, &s->cat_final, w.final_conv, B)) return rc;
+  add_desc(s, s->cat_final, w.final_conv);
+  const int Tt = w.final_conv.T_out, d = cfg.dimension;
+  if (int rc = e->dalloc(&s->x_tr, (size_t)B * Tt * d)) return rc;
+  if (int rc = e->dalloc(&s->xn, (size_t)B * Tt * d)) return rc;
+  if (int rc = e->dalloc(&s->q, (size_t)B * Tt * d)) return rc;
+  if (int rc = e->dalloc(&s->att, (size_t)B * Tt * d)) return rc;
+  if (int rc = e->dalloc(&s->ff, (size_t)B * Tt * cfg.transformer.dim_feedforward)) return rc;
+  if (int rc = alloc_cat(e, &s->cat_ds, w.downsample, B)) return rc;
+  s->ds_desc = (int)s->h_descs.size();
+  add_desc(s, s->cat_ds, w.downsample);
+  if (int rc = e->dalloc(&s->latent, (size_t)B * d)) return rc;
+  if (int rc = e->dalloc(&s->res_first, (size_t)B * cfg.quantizer_dim)) return rc;
+  if (int rc = e->dalloc(&s->res_rest, (size_t)B * cfg.quantizer_dim)) return rc;
+  const int n_tiles = (cfg.quantizer_bins + 15) / 16;
+  if (int rc = e->dalloc(&s->pval, (size_t)n_tiles * B)) return rc;
+  if (int rc = e->dalloc(&s->pidx, (size_t)n_tiles * B)) return rc;
+  if (int rc = e->dalloc(&s->codes, (size_t)B * cfg.quantizer_n_q)) return rc;
+  if (int rc = e->dalloc(&s->mask, B)) return rc;
+  if (int rc = alloc_transformer_state(e, &s->tr, cfg.transformer, B, Tt, false)) return rc;
+  if (int rc = e->upload(&s->descs, s->h_descs.data(), s->h_descs.size())) return rc;
+  s->pcm = s->cat_init + (size_t)w.init_conv.S * w.init_conv.in_c;  // slot 0's frame; slots are bstride apart
+  return 0;
+}
+
+// ----------------------------------------------------------------------------------------------
+// GEMM launch
+// ----------------------------------------------------------------------------------------------
+template <typename WT, typename KVT, int EPI, int NT>
+int launch_gemm_t(dsm_engine* e, hipStream_t st, GemmArgs& a, bool aligned) {
+  const int S = (a.Kpad + DSM_KC - 1) / DSM_KC;
+  if (S > 16) {
+    e->set_error("GEMM K=%d needs more than 16 K-chunks", a.K);
+    return DSM_ERR_INVALID;
+  }
+  const int MT = a.M <= 16 ? 1 : 4;
+  const int tiles16 = (a.N + 15) / 16;  // for the gate a.N is the hidden width: one (gate, up) tile pair per block
+  dim3 grid((EPI == EPI_GATE) ? tiles16 : (tiles16 + NT - 1) / NT, (a.M + 16 * MT - 1) / (16 * MT));
+  dim3 block(64 * S);
+  size_t lds = S > 1 ? (size_t)S * NT * MT * 1024 : 0;
+#define DSM_LAUNCH(MTv, AL) \
+  hipLaunchKernelGGL((gemm_mfma_kernel<WT, KVT, MTv, NT, EPI, AL>), grid, block, lds, st, a)
+  if (MT == 1) {
+    if (aligned) DSM_LAUNCH(1, true); else DSM_LAUNCH(1, false);
+  } else {
+    if (aligned) DSM_LAUNCH(4, true); else DSM_LAUNCH(4, false);
+  }
+#undef DSM_LAUNCH
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+RowMap plain_map(int M, int ld) {
+  RowMap r;
+  r.bstride = 0;
+  r.rpb = M > 0 ? M : 1;
+  r.ld = ld;
+  r.toff = 0;
+  return r;
+}
+RowMap batch_map(long bstride, int rpb, int ld, int toff) {
+  RowMap r;
+  r.bstride = bstride;
+  r.rpb = rpb;
+  r.ld = ld;
+  r.toff = toff;
+  return r;
+}
+
+GemmArgs base_args(const Linear& L, const float* X, RowMap xmap, int M) {
+  GemmArgs a;
+  memset(&a, 0, sizeof a);
+  a.X = X;
+  a.xmap = xmap;
+  a.W = L.w;
+  a.Kpad = L.Kpad;
+  a.K = L.K;
+  a.N = L.N;
+  a.M = M;
+  a.nt_stride = 16;
+  a.bias = L.bias;
+  return a;
+}
+
+template <typename WT>
+int gemm_store(dsm_engine* e, hipStream_t st, GemmArgs& a, bool aligned = true) {
+  return launch_gemm_t<WT, float, EPI_STORE, 1>(e, st, a, aligned);
+}
+
+// conv as a GEMM over the consumer's concat buffer; output goes to Y (raw) and/or Y2 (ELU copy, usually the
+// next conv's concat buffer at time offset S_next)
+int run_conv(dsm_engine* e, hipStream_t st, const ConvGeom& c, const float* cat, int B, float* y, RowMap ymap,
+             float* y2, RowMap y2map, const float* res, RowMap rmap) {
+  const long bstride = (long)(c.S + c.T_in) * c.in_c;
+  GemmArgs a = base_args(c.lin, cat, batch_map(bstride, c.T_out, c.stride * c.in_c, 0), B * c.T_out);
+  a.Y = y;
+  a.ymap = ymap;
+  a.Y2 = y2;
+  a.y2map = y2map;
+  a.res = res;
+  a.rmap = rmap;
+  bool aligned = ((c.stride * c.in_c) % 4 == 0) && (bstride % 4 == 0);
+  return gemm_store<float>(e, st, a, aligned);
+}
+
+}  // namespace
+
+#include "dsm_engine_api.inc"

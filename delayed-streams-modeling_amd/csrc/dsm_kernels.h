@@ -1,0 +1,653 @@
+// dsm_kernels.h — hand-written HIP kernels for gfx950 (MI355X / CDNA4).  Included by dsm_engine.hip.
+//
+// Every kernel follows the canonical reduction orders of dsm_numerics.h so that its f32
+// results are bit-identical to the CPU oracle (oracle/dsm_oracle.c).  Wavefront = 64 lanes.
+//
+//   gemm_mfma_kernel   Y = X . W^T on v_mfma_f32_16x16x4_f32 (exact f32, a k-ordered fmaf chain:
+//                      experiments/numerics_probe.hip).  One workgroup = S waves, wave w owns the
+//                      K-chunk [512w, 512w+512); chunk partials are summed left to right through
+//                      LDS.  Fused epilogues: bias / GELU / layer-scale / residual / ELU copy,
+//                      QKV split + RoPE + ring-cache scatter, SiLU gate, RVQ distance + argmin.
+//   row_norm_kernel    RMSNorm / LayerNorm, one wave per row, xor-butterfly reductions.
+//   attn_kernel        softmax(q.K^T/sqrt(hd) + ring mask).V, one 4-wave workgroup per (slot, head),
+//                      K/V streamed once from HBM with 16-byte loads, scores staged in LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "dsm_numerics.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, 64);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// GEMM
+// ------------------------------------------------------------------------------------------
+enum { EPI_STORE = 0, EPI_QKV = 1, EPI_GATE = 2, EPI_RVQ = 3 };
+
+struct RowMap {  // row m -> element offset: (m / rpb) * bstride + ((m % rpb) + toff) * ld
+  long bstride;
+  int rpb;
+  int ld;
+  int toff;
+  __host__ __device__ long off(int m) const { return (long)(m / rpb) * bstride + (long)((m % rpb) + toff) * ld; }
+};
+
+struct GemmArgs {
+  const float* X;
+  RowMap xmap;
+  const void* W;  // packed [Npad][Kpad], K zero-padded to a multiple of 32, rows to a multiple of 16
+  int Kpad, K, N, M;
+  int nt_stride;  // row distance between the NT n-tiles of one wave (16, or `hidden` for the gate)
+  // EPI_STORE
+  const float* bias;   // [N] or null
+  const float* scale;  // [N] or null (LayerScale)
+  const float* res;    // residual source or null
+  RowMap rmap;
+  float* Y;
+  RowMap ymap;
+  float* Y2;  // optional ELU(y) copy
+  RowMap y2map;
+  int act;  // 0 none, 1 gelu_erf (applied right after bias)
+  // EPI_QKV
+  int d, hd, H, T, ctx;
+  void* kcache;
+  void* vcache;               // [B][H][ctx][hd]
+  const uint32_t* widx;       // [B*T] ring slot written by row (b,t)
+  const float* rope_cs;       // [B*T][hd/2][2] (cos, sin) or null
+  const uint8_t* active;      // [B]
+  // EPI_RVQ
+  float* pval;     // [n_tiles][M]
+  uint32_t* pidx;  // [n_tiles][M]
+};
+
+template <typename WT>
+__device__ __forceinline__ void load_w8(const WT* p, float (&o)[8]);
+template <>
+__device__ __forceinline__ void load_w8<uint16_t>(const uint16_t* p, float (&o)[8]) {
+  uint4 v = *reinterpret_cast<const uint4*>(p);
+  o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xFFFF0000u);
+  o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xFFFF0000u);
+  o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xFFFF0000u);
+  o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xFFFF0000u);
+}
+template <>
+__device__ __forceinline__ void load_w8<float>(const float* p, float (&o)[8]) {
+  float4 a = *reinterpret_cast<const float4*>(p);
+  float4 b = *reinterpret_cast<const float4*>(p + 4);
+  o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+
+__device__ __forceinline__ void store_kv(uint16_t* p, float v) { *p = dsm_f32_to_bf16(v); }
+__device__ __forceinline__ void store_kv(float* p, float v) { *p = v; }
+
+template <typename WT, typename KVT, int MT, int NT, int EPI, bool XALIGNED>
+__global__ void gemm_mfma_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds_part[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, S = blockDim.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int m_base = blockIdx.y * (16 * MT);
+  const int n_base = blockIdx.x * ((EPI == EPI_GATE) ? 16 : 16 * NT);
+  const WT* W = reinterpret_cast<const WT*>(a.W);
+
+  const WT* wrow[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) wrow[nt] = W + (long)(n_base + nt * a.nt_stride + r) * a.Kpad + 8 * q;
+  const float* xrow[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    int m = m_base + 16 * mt + r;
+    m = m < a.M ? m : a.M - 1;  // padded rows re-read the last real row; their results are discarded
+    xrow[mt] = a.X + a.xmap.off(m) + 8 * q;
+  }
+  f32x4 acc[NT][MT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int k0 = wave * DSM_KC;
+  const int k1 = min(k0 + DSM_KC, a.Kpad);
+  for (int kb = k0; kb < k1; kb += 32) {
+    float wa[NT][8], xb[MT][8];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) load_w8<WT>(wrow[nt] + kb, wa[nt]);
+    const bool tail = (kb + 32 > a.K);  // wave-uniform: only the very last block of an odd K
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      if (XALIGNED && !tail) {
+        load_w8<float>(xrow[mt] + kb, xb[mt]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xb[mt][j] = (kb + 8 * q + j < a.K) ? xrow[mt][kb + j] : 0.0f;
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nt][s], xb[mt][s], acc[nt][mt], 0, 0, 0);
+  }
+
+  // ---- split-K combine: ((c0 + c1) + c2) + ... through LDS ----
+  constexpr int TILES = NT * MT;
+  if (S > 1) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        *reinterpret_cast<f32x4*>(&lds_part[(((wave * TILES) + nt * MT + mt) * 64 + lane) * 4]) = acc[nt][mt];
+    __syncthreads();
+    if (EPI == EPI_GATE || EPI == EPI_RVQ) {
+      // these epilogues need all NT tiles of one m-tile in the same wave: wave w' takes m-tiles w', w'+S, ...
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        if ((mt % S) != wave) continue;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          f32x4 tot = *reinterpret_cast<f32x4*>(&lds_part[((nt * MT + mt) * 64 + lane) * 4]);
+          for (int w = 1; w < S; ++w) {
+            f32x4 p = *reinterpret_cast<f32x4*>(&lds_part[(((w * TILES) + nt * MT + mt) * 64 + lane) * 4]);
+            tot = tot + p;
+          }
+          acc[nt][mt] = tot;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          if (((nt * MT + mt) % S) != wave) continue;
+          f32x4 tot = *reinterpret_cast<f32x4*>(&lds_part[((nt * MT + mt) * 64 + lane) * 4]);
+          for (int w = 1; w < S; ++w) {
+            f32x4 p = *reinterpret_cast<f32x4*>(&lds_part[(((w * TILES) + nt * MT + mt) * 64 + lane) * 4]);
+            tot = tot + p;
+          }
+          acc[nt][mt] = tot;
+        }
+    }
+  }
+
+  // ---- epilogue: lane holds rows n = n_tile + 4q + i (i = 0..3) of column m = m_tile + r ----
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m_base + 16 * mt + r;
+    if (EPI == EPI_GATE) {
+      if (S > 1 && (mt % S) != wave) continue;
+      if (m >= a.M) continue;
+      const int n = n_base + 4 * q;
+      float* y = a.Y + a.ymap.off(m) + n;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (n + i < a.N) y[i] = dsm_silu(acc[0][mt][i]) * acc[NT - 1][mt][i];
+      continue;
+    }
+    if (EPI == EPI_RVQ) {
+      if (S > 1 && (mt % S) != wave) continue;
+      // dist = c2[n] - dot; argmin over the tile's 16*NT rows, first occurrence on ties
+      float bv = DSM_INF_F;
+      uint32_t bi = 0xFFFFFFFFu;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          int n = n_base + nt * a.nt_stride + 4 * q + i;
+          float dist = a.bias[n] - acc[nt][mt][i];
+          if (n < a.N && (dist < bv || (dist == bv && (uint32_t)n < bi))) { bv = dist; bi = (uint32_t)n; }
+        }
+#pragma unroll
+      for (int off = 16; off <= 32; off <<= 1) {
+        float ov = __shfl_xor(bv, off, 64);
+        uint32_t oi = __shfl_xor(bi, off, 64);
+        if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+      }
+      if (q == 0 && m < a.M) {
+        a.pval[(long)blockIdx.x * a.M + m] = bv;
+        a.pidx[(long)blockIdx.x * a.M + m] = bi;
+      }
+      continue;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      if (S > 1 && ((nt * MT + mt) % S) != wave) continue;
+      if (m >= a.M) continue;
+      const int n = n_base + nt * a.nt_stride + 4 * q;
+      if (n >= a.N) continue;
+      f32x4 v = acc[nt][mt];
+      if (EPI == EPI_STORE) {
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float t = v[i];
+          if (n + i < a.N) {
+            if (a.bias) t = t + a.bias[n + i];
+            if (a.act == 1) t = dsm_gelu_erf(t);
+            if (a.scale) t = t * a.scale[n + i];
+          }
+          o[i] = t;
+        }
+        if (a.res) {
+          const float* rp = a.res + a.rmap.off(m) + n;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (n + i < a.N) o[i] = rp[i] + o[i];
+        }
+        if (a.Y) {
+          float* y = a.Y + a.ymap.off(m) + n;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (n + i < a.N) y[i] = o[i];
+        }
+        if (a.Y2) {
+          float* y2 = a.Y2 + a.y2map.off(m) + n;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (n + i < a.N) y2[i] = dsm_elu(o[i]);
+        }
+      } else if (EPI == EPI_QKV) {
+        // n in [0, 3d): part 0 = q, 1 = k, 2 = v; (b,t,3,H,hd) layout — core/batched_transformer.rs:77-82
+        const int part = n / a.d, c = n - part * a.d, h = c / a.hd, i0 = c - h * a.hd;
+        const int b = m / a.T;
+        float o[4] = {v[0], v[1], v[2], v[3]};
+        if (part < 2 && a.rope_cs) {  // rope_i on interleaved pairs — core/transformer.rs:373-377
+          const float* cs = a.rope_cs + ((long)m * (a.hd / 2) + (i0 >> 1)) * 2;
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            float co = cs[2 * p], si = cs[2 * p + 1];
+            float x0 = v[2 * p], x1 = v[2 * p + 1];
+            float t0 = x0 * co, t1 = x1 * si, t2 = x0 * si, t3 = x1 * co;
+            o[2 * p] = t0 - t1;
+            o[2 * p + 1] = t2 + t3;
+          }
+        }
+        if (part == 0) {
+          float* y = a.Y + (long)m * a.d + c;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) y[i] = o[i];
+        } else if (a.active[b]) {  // inactive slots: the reference scatters garbage that is never read
+          KVT* cache = reinterpret_cast<KVT*>(part == 1 ? a.kcache : a.vcache);
+          KVT* dst = cache + (((long)b * a.H + h) * a.ctx + a.widx[m]) * a.hd + i0;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) store_kv(dst + i, o[i]);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Row norms — one wave per row.  mode 1: RmsNorm (core/batched_transformer.rs:194-198),
+// mode 0: LayerNorm (core/batched_transformer.rs:200-222).
+// ------------------------------------------------------------------------------------------
+__global__ void row_norm_kernel(float* __restrict__ y, const float* __restrict__ x, const float* __restrict__ w,
+                                const float* __restrict__ b, int rows, int d, float eps, int rms) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (long)row * d;
+  float s = 0.0f, s2 = 0.0f;
+  for (int it = 0; it * 256 < d; ++it) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int i = it * 256 + 4 * lane + j;
+      if (i < d) {
+        float v = xr[i];
+        s = s + v;
+        s2 = DSM_FMAF(v, v, s2);
+      }
+    }
+  }
+  s2 = wave_sum64(s2);
+  float* yr = y + (long)row * d;
+  if (rms) {
+    float m = sqrtf(s2 / (float)d + eps);
+    for (int i = lane; i < d; i += 64) yr[i] = (xr[i] / m) * w[i];
+  } else {
+    s = wave_sum64(s);
+    float mean = s / (float)d;
+    float var = s2 / (float)d - mean * mean;
+    float inv = 1.0f / sqrtf(var + eps);
+    for (int i = lane; i < d; i += 64) yr[i] = ((xr[i] - mean) * inv) * w[i] + b[i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Attention over the ring cache — core/batched_transformer.rs:107-113 + mask semantics of
+// core/kv_cache.rs:119-237 in closed form: slot j is visible to query t iff
+//   j <= e1  and  (e1 - j) mod ctx >= T-1-t,   e1 = start_pos + T - 1.
+// One workgroup (4 waves) per (slot b, head h).  LPK = HD/8 lanes per key, G = 64/LPK keys per
+// wave-instruction, key j -> wave (j/G)%4, lane group j%G (canonical order, dsm_numerics.h).
+// ------------------------------------------------------------------------------------------
+template <typename KVT, int HD, int T>
+__global__ __launch_bounds__(256) void attn_kernel(float* __restrict__ out, const float* __restrict__ qbuf,
+                                                   const KVT* __restrict__ kcache, const KVT* __restrict__ vcache,
+                                                   const uint32_t* __restrict__ start_pos,
+                                                   const uint8_t* __restrict__ active, int H, int ctx, int d) {
+  constexpr int NW = 4, LPK = HD / 8, G = 64 / LPK;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  if (!active[b]) return;  // inactive slots: output unused by the reference (core/asr.rs:221-223)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane / LPK, li = lane % LPK;
+  float* sc = lds;                       // [T][ctx]
+  float* red = lds + T * ctx;            // [NW][T][HD] then small scratch
+  float* scratch = red + NW * T * HD;    // [16]
+
+  const uint32_t sp = start_pos[b];
+  const long e1 = (long)sp + T - 1;
+  const int nvalid = (int)((e1 + 1 < (long)ctx) ? e1 + 1 : ctx);  // slots > e1 were never written
+  const float scale = (float)(1.0 / sqrt((double)HD));
+
+  float qv[T][8];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const float* qp = qbuf + ((long)(b * T + t)) * d + h * HD + 8 * li;
+    float4 q0 = *reinterpret_cast<const float4*>(qp), q1 = *reinterpret_cast<const float4*>(qp + 4);
+    qv[t][0] = q0.x; qv[t][1] = q0.y; qv[t][2] = q0.z; qv[t][3] = q0.w;
+    qv[t][4] = q1.x; qv[t][5] = q1.y; qv[t][6] = q1.z; qv[t][7] = q1.w;
+  }
+  const KVT* Kb = kcache + ((long)b * H + h) * ctx * HD;
+  const KVT* Vb = vcache + ((long)b * H + h) * ctx * HD;
+
+  // ---- phase 1: scores ----
+  for (int j0 = wave * G; j0 < nvalid; j0 += NW * G) {
+    const int j = j0 + g;
+    if (j < nvalid) {
+      float kv[8];
+      load_w8<KVT>(Kb + (long)j * HD + 8 * li, kv);
+      const long delta = (e1 - j) % ctx;
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        float p = 0.0f;
+#pragma unroll
+        for (int dd = 0; dd < 8; ++dd) p = DSM_FMAF(qv[t][dd], kv[dd], p);
+#pragma unroll
+        for (int off = LPK / 2; off >= 1; off >>= 1) p = p + __shfl_xor(p, off, 64);
+        if (li == 0) sc[t * ctx + j] = (delta >= (long)(T - 1 - t)) ? p * scale : -DSM_INF_F;
+      }
+    } else {
+      // keep the shuffles convergent for partially filled last iterations
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        float p = 0.0f;
+#pragma unroll
+        for (int off = LPK / 2; off >= 1; off >>= 1) p = p + __shfl_xor(p, off, 64);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 1.5: softmax statistics (softmax_last_dim) ----
+  float lsum[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    float m = -DSM_INF_F;
+    for (int j = tid; j < nvalid; j += 256) m = fmaxf(m, sc[t * ctx + j]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if (lane == 0) scratch[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3]));
+    __syncthreads();
+    float tp = 0.0f;
+    for (int j = tid; j < nvalid; j += 256) {
+      float p = dsm_expf(sc[t * ctx + j] - m);
+      sc[t * ctx + j] = p;
+      tp = tp + p;
+    }
+    tp = wave_sum64(tp);
+    if (lane == 0) scratch[4 + wave] = tp;
+    __syncthreads();
+    lsum[t] = ((scratch[4] + scratch[5]) + scratch[6]) + scratch[7];
+    __syncthreads();
+  }
+
+  // ---- phase 2: P.V ----
+  float acc[T][8];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int dd = 0; dd < 8; ++dd) acc[t][dd] = 0.0f;
+  for (int j0 = wave * G; j0 < nvalid; j0 += NW * G) {
+    const int j = j0 + g;
+    if (j < nvalid) {
+      float vv[8];
+      load_w8<KVT>(Vb + (long)j * HD + 8 * li, vv);
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        float wgt = sc[t * ctx + j] / lsum[t];
+#pragma unroll
+        for (int dd = 0; dd < 8; ++dd) acc[t][dd] = DSM_FMAF(wgt, vv[dd], acc[t][dd]);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int dd = 0; dd < 8; ++dd) {
+      float v = acc[t][dd];
+#pragma unroll
+      for (int off = 32; off >= LPK; off >>= 1) v = v + __shfl_xor(v, off, 64);
+      acc[t][dd] = v;
+    }
+  if (g == 0) {
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int dd = 0; dd < 8; ++dd) red[(wave * T + t) * HD + 8 * li + dd] = acc[t][dd];
+  }
+  __syncthreads();
+  for (int i = tid; i < T * HD; i += 256) {
+    int t = i / HD, dd = i % HD;
+    float tot = ((red[(0 * T + t) * HD + dd] + red[(1 * T + t) * HD + dd]) + red[(2 * T + t) * HD + dd]) +
+                red[(3 * T + t) * HD + dd];
+    out[((long)(b * T + t)) * d + h * HD + dd] = tot;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// ScatteredCacheBuilder step on the device (core/kv_cache.rs:119-237): write slots, start
+// positions, advance for active slots, and the RoPE table for the positions AFTER the advance
+// (core/batched_transformer.rs:438-447).
+// ------------------------------------------------------------------------------------------
+__global__ void kv_builder_kernel(uint32_t* __restrict__ pos, uint32_t* __restrict__ idx,
+                                  const uint8_t* __restrict__ active, uint32_t* __restrict__ start_pos,
+                                  uint32_t* __restrict__ widx, float* __restrict__ rope_cs,
+                                  const float* __restrict__ inv_freq, int B, int T, int ctx, int hd) {
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  __shared__ uint32_t s_pos_after;
+  if (threadIdx.x == 0) {
+    uint32_t p = pos[b], i = idx[b];
+    start_pos[b] = p;
+    for (int t = 0; t < T; ++t) widx[b * T + t] = active[b] ? (uint32_t)((i + t) % ctx) : i;
+    if (active[b]) {
+      pos[b] = p + T;
+      idx[b] = (uint32_t)((i + T) % ctx);
+      p += T;
+    }
+    s_pos_after = p;
+  }
+  __syncthreads();
+  if (rope_cs) {
+    const int half = hd / 2;
+    for (int e = threadIdx.x; e < T * half; e += blockDim.x) {
+      int t = e / half, i = e % half;
+      float ang = (float)(s_pos_after + (uint32_t)t) * inv_freq[i];
+      float s, c;
+      dsm_sincosf(ang, &s, &c);
+      rope_cs[((long)(b * T + t) * half + i) * 2] = c;
+      rope_cs[((long)(b * T + t) * half + i) * 2 + 1] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// ASR glue — core/asr.rs:165-189 (token shift, pad select) + core/lm.rs:983-995 (embedding sum)
+// one workgroup per slot.
+// ------------------------------------------------------------------------------------------
+__global__ void lm_input_kernel(float* __restrict__ x, const uint16_t* __restrict__ text_emb,
+                                const uint16_t* __restrict__ audio_emb /* [nc][audio_vocab][d] */,
+                                const uint32_t* __restrict__ codes /* [B][nc] */, uint32_t* __restrict__ next_cb,
+                                const uint32_t* __restrict__ text_token, const uint8_t* __restrict__ first_step,
+                                const uint8_t* __restrict__ active, int nc, int d, int audio_vocab,
+                                uint32_t pad_tok, uint32_t start_tok) {
+  const int b = blockIdx.x;
+  __shared__ uint32_t toks[64];
+  const bool first = first_step[b] != 0;
+  if (threadIdx.x < nc) {
+    uint32_t prev = next_cb[b * nc + threadIdx.x];
+    toks[threadIdx.x] = first ? pad_tok : prev;
+    if (active[b]) next_cb[b * nc + threadIdx.x] = codes[b * nc + threadIdx.x];
+  }
+  __syncthreads();
+  const uint32_t tt = first ? start_tok : text_token[b];
+  for (int j = threadIdx.x; j < d; j += blockDim.x) {
+    float e = dsm_bf16_to_f32(text_emb[(long)tt * d + j]);
+    for (int i = 0; i < nc; ++i) e = e + dsm_bf16_to_f32(audio_emb[((long)i * audio_vocab + toks[i]) * d + j]);
+    x[(long)b * d + j] = e;
+  }
+}
+
+// argmax over the text logits (first occurrence on ties, core/asr.rs:208-210) + item-state update
+__global__ void lm_argmax_kernel(const float* __restrict__ logits, int V, uint32_t* __restrict__ text_out,
+                                 uint32_t* __restrict__ text_token, uint8_t* __restrict__ first_step,
+                                 const uint8_t* __restrict__ active) {
+  const int b = blockIdx.x;
+  const float* lg = logits + (long)b * V;
+  float bv = -DSM_INF_F;
+  int bi = 0x7FFFFFFF;
+  for (int j = threadIdx.x; j < V; j += blockDim.x) {
+    float v = lg[j];
+    if (v > bv || (v == bv && j < bi)) { bv = v; bi = j; }
+  }
+  __shared__ float sv[256];
+  __shared__ int si[256];
+  sv[threadIdx.x] = bv;
+  si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int off = blockDim.x / 2; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      float ov = sv[threadIdx.x + off];
+      int oi = si[threadIdx.x + off];
+      if (ov > sv[threadIdx.x] || (ov == sv[threadIdx.x] && oi < si[threadIdx.x])) {
+        sv[threadIdx.x] = ov;
+        si[threadIdx.x] = oi;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    uint32_t tok = (uint32_t)si[0];
+    text_out[b] = tok;
+    if (active[b]) {
+      text_token[b] = tok;
+      first_step[b] = 0;
+    }
+  }
+}
+
+// extra heads: f32 softmax over `dim` classes, class-0 probability -> prs[head][slot] (core/asr.rs:195-203)
+__global__ void extra_heads_kernel(const float* __restrict__ eh /* [B][nh*dim] */, float* __restrict__ prs, int B,
+                                   int nh, int dim) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * nh) return;
+  int b = i / nh, h = i % nh;
+  const float* lg = eh + ((long)b * nh + h) * dim;
+  float m = lg[0];
+  for (int k = 1; k < dim; ++k) m = lg[k] > m ? lg[k] : m;
+  float sum = 0.0f, e0 = 0.0f;
+  for (int k = 0; k < dim; ++k) {
+    float e = dsm_expf(lg[k] - m);
+    if (k == 0) e0 = e;
+    sum = sum + e;
+  }
+  prs[(long)h * B + b] = e0 / sum;
+}
+
+// ------------------------------------------------------------------------------------------
+// Streaming-conv state: in-place shift of the consumer's concat buffer after it ran
+// (core/conv.rs:335-367).  desc[i] = {ptr, state_len S, step frames T, channels C, batch stride}.
+// active slots: cat[b][0..S) = cat[b][T..T+S); inactive: unchanged (zeroed on the first call).
+// ------------------------------------------------------------------------------------------
+struct ConvStateDesc {
+  float* cat;
+  long bstride;
+  int S, T, C, replicate;
+};
+
+__global__ void conv_state_shift_kernel(const ConvStateDesc* __restrict__ descs, const uint8_t* __restrict__ active,
+                                        int first_call) {
+  const ConvStateDesc dsc = descs[blockIdx.y];
+  const int b = blockIdx.x;
+  float* base = dsc.cat + (long)b * dsc.bstride;
+  const int n = dsc.S * dsc.C;
+  if (active[b]) {
+    const float* src = base + (long)dsc.T * dsc.C;
+    // S <= T for every conv of the model, so source and destination do not overlap
+    for (int i = threadIdx.x; i < n; i += blockDim.x) base[i] = src[i];
+  } else if (first_call) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) base[i] = 0.0f;
+  }
+}
+
+// first call of a replicate-padded conv (ConvDownsample1d, core/conv.rs:318-327,530): the left pad
+// repeats the first input frame of every slot
+__global__ void conv_replicate_init_kernel(ConvStateDesc dsc) {
+  const int b = blockIdx.x;
+  float* base = dsc.cat + (long)b * dsc.bstride;
+  const float* first = base + (long)dsc.S * dsc.C;
+  for (int i = threadIdx.x; i < dsc.S * dsc.C; i += blockDim.x) base[i] = first[i % dsc.C];
+}
+
+__global__ void conv_state_reset_kernel(const ConvStateDesc* __restrict__ descs, int slot) {
+  const ConvStateDesc dsc = descs[blockIdx.x];
+  float* base = dsc.cat + (long)slot * dsc.bstride;
+  for (int i = threadIdx.x; i < dsc.S * dsc.C; i += blockDim.x) base[i] = 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------
+// RVQ select: reduce the per-tile (dist, idx) partials, emit the code, update the residual
+// (core/quantization.rs:219-229).  One workgroup per row.
+// ------------------------------------------------------------------------------------------
+__global__ void rvq_select_kernel(const float* __restrict__ pval, const uint32_t* __restrict__ pidx, int n_tiles,
+                                  int M, uint32_t* __restrict__ codes, int code_stride, int code_off,
+                                  float* __restrict__ residual, const float* __restrict__ E, int dim, int ldE) {
+  const int m = blockIdx.x;
+  __shared__ uint32_t s_code;
+  if (threadIdx.x < 64) {
+    float bv = DSM_INF_F;
+    uint32_t bi = 0xFFFFFFFFu;
+    for (int t = threadIdx.x; t < n_tiles; t += 64) {
+      float v = pval[(long)t * M + m];
+      uint32_t i = pidx[(long)t * M + m];
+      if (v < bv || (v == bv && i < bi)) { bv = v; bi = i; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      float ov = __shfl_xor(bv, off, 64);
+      uint32_t oi = __shfl_xor(bi, off, 64);
+      if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (threadIdx.x == 0) {
+      s_code = bi;
+      codes[(long)m * code_stride + code_off] = bi;
+    }
+  }
+  __syncthreads();
+  const uint32_t c = s_code;
+  for (int i = threadIdx.x; i < dim; i += blockDim.x)
+    residual[(long)m * dim + i] = residual[(long)m * dim + i] - E[(long)c * ldE + i];
+}
+
+__global__ void fill_u32_kernel(uint32_t* p, uint32_t v, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}

@@ -1,0 +1,89 @@
+"""GPU parity: the HIP engine (through the C ABI) against the CPU oracle, bit for bit.
+
+Integer outputs (Mimi codes, text tokens) and every float tap are compared with assert-equal:
+the kernels follow the canonical reduction orders of csrc/dsm_numerics.h, so there is no
+tolerance to tune.  Inactive slots are excluded where the reference itself ignores them
+(core/asr.rs:177-183,221-223)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def run_pair(dsm, orc, cfg, B, lm, mimi, steps, mask_fn, resets=None, pcm_seed=1000, via_step_pcm=False):
+    from dsm_amd import synth
+    eng = dsm.AsrEngine(cfg, B, lm, mimi)
+    ora = orc.OracleAsr(cfg, B, lm, mimi)
+    pcm = synth.synth_pcm(B, steps, seed=pcm_seed)
+    resets = resets or {}
+    log = []
+    for s in range(steps):
+        for slot in resets.get(s, []):
+            eng.reset_batch_idx(slot)
+            ora.reset_batch_idx(slot)
+            if not via_step_pcm:
+                eng.mimi_reset_batch_idx(slot)
+                ora.mimi_reset_batch_idx(slot, side=0)
+        mask = np.asarray(mask_fn(s), dtype=np.uint8)
+        act = mask.astype(bool)
+        if via_step_pcm:
+            ec, et, ep = eng.step_pcm(pcm[s], mask)
+            oc, ot, op = ora.step_pcm(pcm[s], mask)
+        else:
+            ec = eng.encode_step(pcm[s], mask)
+            oc = ora.encode_step(pcm[s], mask)
+            lat_e = eng.debug_read("mimi.latent", B * cfg.mimi.dimension).reshape(B, -1)
+            lat_o = ora.debug_read("mimi.latent", B * cfg.mimi.dimension).reshape(B, -1)
+            assert np.array_equal(lat_e[act].view(np.uint32), lat_o[act].view(np.uint32)), f"latent differs at step {s}"
+            # feed the LM the ORACLE's codes for every slot so that inactive-slot garbage cannot leak in
+            et, ep = eng.step_tokens(oc, mask)
+            ot, op = ora.step_tokens(oc, mask)
+        assert np.array_equal(ec[act], oc[act]), f"codes differ at step {s}:\n{ec[act]}\n{oc[act]}"
+        hid_e = eng.debug_read("lm.hidden", B * cfg.lm.d_model).reshape(B, -1)
+        hid_o = ora.debug_read("lm.hidden", B * cfg.lm.d_model).reshape(B, -1)
+        assert np.array_equal(hid_e[act].view(np.uint32), hid_o[act].view(np.uint32)), f"lm.hidden differs at step {s}"
+        lg_e = eng.debug_read("lm.logits", B * cfg.text_out_vocab_size).reshape(B, -1)
+        lg_o = ora.debug_read("lm.logits", B * cfg.text_out_vocab_size).reshape(B, -1)
+        assert np.array_equal(lg_e[act].view(np.uint32), lg_o[act].view(np.uint32)), f"logits differ at step {s}"
+        assert np.array_equal(et[act], ot[act]), f"text tokens differ at step {s}"
+        assert np.array_equal(ep[:, act].view(np.uint32), op[:, act].view(np.uint32)), f"vad prs differ at step {s}"
+        assert eng.poll_msgs() == ora.poll_msgs(), f"AsrMsg lists differ at step {s}"
+        log.append((ec.copy(), et.copy()))
+    eng.close()
+    ora.close()
+    return log
+
+
+def test_tiny_all_active(gpu, dsm, lib, orc, tiny_weights):
+    cfg = dsm.config_tiny()
+    run_pair(dsm, orc, cfg, 3, *tiny_weights, steps=30, mask_fn=lambda s: [1, 1, 1])
+
+
+def test_tiny_masks_and_resets(gpu, dsm, lib, orc, tiny_weights):
+    """Mixed masks, ring wrap (LM ctx 12, Mimi ctx 10) and mid-stream slot resets."""
+    cfg = dsm.config_tiny()
+    rng = np.random.default_rng(7)
+    masks = (rng.random((40, 5)) < 0.7).astype(np.uint8)
+    masks[:, 0] = 1
+    run_pair(dsm, orc, cfg, 5, *tiny_weights, steps=40, mask_fn=lambda s: masks[s],
+             resets={9: [1], 17: [0, 3], 18: [3], 30: [2]})
+
+
+def test_tiny_step_pcm(gpu, dsm, lib, orc, tiny_weights):
+    """asr::State::step_pcm path (model-side Mimi state)."""
+    cfg = dsm.config_tiny()
+    run_pair(dsm, orc, cfg, 2, *tiny_weights, steps=8, mask_fn=lambda s: [1, s % 3 != 1], via_step_pcm=True,
+             resets={5: [1]})
+
+
+def test_tiny_f32_kv(gpu, dsm, lib, orc, tiny_weights):
+    """kv_bf16 = 0: the Candle CPU path's dtype (f32 ring cache)."""
+    cfg = dsm.config_tiny(kv_bf16=0)
+    run_pair(dsm, orc, cfg, 2, *tiny_weights, steps=16, mask_fn=lambda s: [1, 1])
+
+
+def test_tiny_batch_sizes(gpu, dsm, lib, orc, tiny_weights):
+    """B = 1 (single m-tile path) and B = 17 (ragged last m-tile)."""
+    cfg = dsm.config_tiny()
+    for B in (1, 17):
+        run_pair(dsm, orc, cfg, B, *tiny_weights, steps=4, mask_fn=lambda s: [1] * B)
