@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py — per-80 ms-frame batched STT step on MI355X (Mimi encode + delayed-streams LM decode).
+
+One "step" = one 80 ms frame for every stream slot of the batch: dsm_asr_step_pcm_dev = SEANet
+encoder + Mimi transformer + RVQ encode + LM step (16 layers over the full ring KV cache) + argmax,
+with PCM, mask and every state tensor resident in HBM.  Workload: stt-1b-en_fr, bf16 weights / bf16
+KV, batch 64 per GPU (BASELINE.json configs[1]); synthetic Philox weights and PCM (no checkpoints
+offline).  Before the warmup an UNTIMED fill of `context` steps brings every slot's ring cache to
+steady state, so each timed step streams the whole 750-frame KV cache.
+
+  python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run)
+
+Prints ONE JSON line on rank 0.  Multi-GPU: independent stream batches per GPU (weak scaling), no
+per-step collective; the shared weights are fanned out once at load with an RCCL broadcast.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=64, help="stream slots per GPU")
+    ap.add_argument("--config", default="stt-1b-en_fr", choices=["stt-1b-en_fr", "stt-2.6b-en", "tiny"])
+    ap.add_argument("--no-fill", action="store_true", help="skip the untimed ring-cache fill (debug only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--weights-dir", default=os.environ.get("DSM_WEIGHTS_DIR", "/tmp/dsm_weights"))
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, B, lm_path, mimi_path, n_steps):
+    """The oracle (CPU restatement, kind "port") timed on the host cores on a bounded sample of the same
+    workload: n_steps frames of the same batch at steady-state cache fill is not reachable on a CPU in
+    seconds, so the sample is the first n_steps frames after reset (short KV: favours the CPU)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle
+    from dsm_amd import synth
+    oracle.build()
+    t0 = time.time()
+    o = oracle.OracleAsr(cfg, B, lm_path, mimi_path)
+    load_s = time.time() - t0
+    pcm = synth.synth_pcm(B, n_steps + 1, seed=1000)
+    mask = np.ones(B, dtype=np.uint8)
+    o.step_pcm(pcm[0], mask)  # untimed first touch
+    t0 = time.time()
+    for s in range(n_steps):
+        o.step_pcm(pcm[1 + s], mask)
+    dt = (time.time() - t0) / n_steps
+    o.close()
+    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    return {"value": B * 0.08 / dt, "unit": "x realtime (stream-seconds of audio per wall second)",
+            "cores": cores, "kind": "port",
+            "sample": f"{n_steps} frames x {B} streams right after reset (KV fill <= {n_steps + 1}), "
+                      f"{dt * 1000:.0f} ms/step, oracle load {load_s:.0f} s; Candle itself cannot be built offline"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import dsm_amd
+    from dsm_amd import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    cfg = {"stt-1b-en_fr": dsm_amd.config_stt_1b_en_fr, "stt-2.6b-en": dsm_amd.config_stt_2_6b_en,
+           "tiny": dsm_amd.config_tiny}[args.config]()
+    B = args.batch
+    tag = args.config
+    # rank 0 writes the synthetic checkpoint; the other ranks get the bytes over RCCL (the only collective)
+    if rank == 0:
+        lm_path, mimi_path = synth.make_synth_weights(cfg, args.weights_dir, tag=tag)
+    bcast_ms = None
+    if world > 1:
+        from dsm_amd import sharding
+        paths = []
+        for which in ("lm", "mimi"):
+            raw = np.fromfile(lm_path if which == "lm" else mimi_path, dtype=np.uint8) if rank == 0 else np.zeros(0, np.uint8)
+            torch.cuda.synchronize()
+            t0 = time.time()
+            got = sharding.broadcast_bytes(raw, 0, dist, device=dev)  # RCCL over xGMI: the only collective
+            bcast_ms = (bcast_ms or 0.0) + (time.time() - t0) * 1000
+            if rank != 0:
+                p = os.path.join(args.weights_dir, f"{tag}.rank{rank}.{which}.safetensors")
+                os.makedirs(args.weights_dir, exist_ok=True)
+                got.tofile(p)
+                paths.append(p)
+            del got
+        if rank != 0:
+            lm_path, mimi_path = paths
+    eng = dsm_amd.AsrEngine(cfg, B, lm_path, mimi_path, device_id=local_rank)
+    if world > 1 and rank != 0:
+        for p in (lm_path, mimi_path):
+            os.remove(p)
+
+    ctx = cfg.lm.context
+    n_pcm = 16
+    pcm = torch.from_numpy(synth.synth_pcm(B, n_pcm, seed=1000 + 7919 * rank)).to(dev)  # [n_pcm, B, 1920]
+    mask = torch.ones(B, dtype=torch.uint8, device=dev)
+    text = torch.zeros(B, dtype=torch.int32, device=dev)
+    prs = torch.zeros(max(cfg.extra_heads_num, 1) * B, dtype=torch.float32, device=dev)
+    codes = torch.zeros(B * cfg.audio_codebooks, dtype=torch.int32, device=dev)
+
+    def step(i):
+        eng.step_pcm_dev(pcm[i % n_pcm].data_ptr(), mask.data_ptr(), codes.data_ptr(), text.data_ptr(), prs.data_ptr())
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    it = 0
+    if not args.no_fill:
+        for _ in range(ctx):
+            step(it)
+            it += 1
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step(it)
+        it += 1
+    # ---- timed region: exactly K steps, dominant kernel bracketed by HIP events on its own stream ----
+    eng.prof_enable(["attn_lm"])
+    eng.prof_read()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(it)
+        it += 1
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = eng.prof_read()
+    eng.prof_enable([])
+    dt_t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
+    dt = float(dt_t.item())
+    ms_per_step = dt / args.steps * 1000.0
+
+    # per-class device time of one extra pass (not part of `value`): where a step goes
+    eng.prof_enable(dsm_amd.PROF_TAGS)
+    eng.prof_read()
+    for _ in range(5):
+        step(it)
+        it += 1
+    breakdown = {k: round(v[0] / 5.0, 1) for k, v in eng.prof_read().items()}
+    eng.prof_enable([])
+
+    if rank == 0:
+        H, hd, L = cfg.lm.num_heads, cfg.lm.d_model // cfg.lm.num_heads, cfg.lm.num_layers
+        kv_b = 2 if cfg.kv_bf16 else 4
+        fill = ctx if not args.no_fill else min(it, ctx)
+        # algorithmic bytes of ONE attention launch (one layer): K and V of every (slot, head) once + q in + out
+        attn_bytes = B * H * (2 * fill * hd * kv_b + 2 * hd * 4)
+        attn_us, attn_n = prof["attn_lm"]
+        attn_avg_us = attn_us / max(attn_n, 1)
+        achieved = attn_bytes / (attn_avg_us * 1e-6) / 1e9 if attn_n else 0.0
+        out = {
+            "metric": "real-time stream throughput, %s @ bs=%d per GPU (Mimi encode + LM decode per 80 ms frame)" % (args.config, B),
+            "value": world * B * 0.08 / (ms_per_step / 1000.0),
+            "unit": "x realtime (stream-seconds of audio per wall second)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16 weights + bf16 KV, f32 activations/accumulate", "data": "synthetic",
+            "rtf": 80.0 / ms_per_step,
+            "config": {"workload": "%s batch=%d streaming, ring KV cache full (%d frames), Mimi encode + LM decode HIP path"
+                                   % (args.config, B, fill),
+                       "streams_per_gpu": B, "parallelism": "replicas x%d (independent stream batches)" % world,
+                       "weights_broadcast_ms": bcast_ms},
+            "roofline": {"bound": "hbm", "kernel": "attn_kernel<bf16,hd%d,T1> (LM ring-cache attention, %d launches/step)" % (hd, L),
+                         "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                         "algorithmic_bytes_per_launch": attn_bytes, "avg_launch_us": attn_avg_us,
+                         "launches_timed": int(attn_n), "traffic": None},
+            "step_breakdown_us": breakdown,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg, B, lm_path, mimi_path, args.cpu_steps)
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

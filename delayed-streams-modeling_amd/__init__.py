@@ -68,8 +68,9 @@ ABI_SYMBOLS = [
     "dsm_asr_create", "dsm_destroy", "dsm_last_error", "dsm_mimi_encode_step", "dsm_asr_step_tokens",
     "dsm_asr_step_pcm", "dsm_asr_poll_msgs", "dsm_asr_reset_slot", "dsm_mimi_reset_slot", "dsm_sync",
     "dsm_get_metrics", "dsm_batch_size", "dsm_n_q", "dsm_mimi_encode_step_dev", "dsm_asr_step_tokens_dev",
-    "dsm_streams_join", "dsm_debug_read",
+    "dsm_streams_join", "dsm_debug_read", "dsm_asr_step_pcm_dev", "dsm_prof_enable", "dsm_prof_read",
 ]
+PROF_TAGS = ["attn_lm", "gemm_lm", "attn_mimi", "gemm_mimi", "rvq", "other"]
 
 _lib = None
 
@@ -109,10 +110,13 @@ def load_library(path=None):
     lib.dsm_asr_step_tokens_dev.argtypes = [vp, vp, vp, vp, vp]
     lib.dsm_streams_join.argtypes = [vp]
     lib.dsm_debug_read.argtypes = [vp, C.c_char_p, fp, C.c_size_t]
+    lib.dsm_asr_step_pcm_dev.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.dsm_prof_enable.argtypes = [vp, C.c_uint]
+    lib.dsm_prof_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     for name in ("dsm_mimi_encode_step", "dsm_asr_step_tokens", "dsm_asr_step_pcm", "dsm_asr_poll_msgs",
                  "dsm_asr_reset_slot", "dsm_mimi_reset_slot", "dsm_sync", "dsm_get_metrics", "dsm_batch_size",
                  "dsm_n_q", "dsm_mimi_encode_step_dev", "dsm_asr_step_tokens_dev", "dsm_streams_join",
-                 "dsm_debug_read"):
+                 "dsm_debug_read", "dsm_asr_step_pcm_dev", "dsm_prof_enable", "dsm_prof_read"):
         getattr(lib, name).restype = C.c_int
     if path is None:
         _lib = lib
@@ -277,3 +281,18 @@ class AsrEngine:
 
     def streams_join(self):
         self._check(self.lib.dsm_streams_join(self.h))
+
+    def step_pcm_dev(self, d_pcm, d_mask, d_codes=None, d_text=None, d_prs=None):
+        self._check(self.lib.dsm_asr_step_pcm_dev(self.h, d_pcm, d_mask, d_codes, d_text, d_prs))
+
+    def prof_enable(self, tags):
+        mask = 0
+        for t in tags:
+            mask |= 1 << PROF_TAGS.index(t)
+        self._check(self.lib.dsm_prof_enable(self.h, mask))
+
+    def prof_read(self):
+        tot = (C.c_double * len(PROF_TAGS))()
+        cnt = (C.c_uint64 * len(PROF_TAGS))()
+        self._check(self.lib.dsm_prof_read(self.h, tot, cnt))
+        return {t: (tot[i], cnt[i]) for i, t in enumerate(PROF_TAGS)}

@@ -157,6 +157,39 @@ struct dsm_engine {
   std::vector<dsm_asr_msg> msgs;
   std::vector<uint32_t> msg_tokens;
   dsm_metrics metrics{};
+  // per-kernel-class event timing (dsm_prof_*)
+  unsigned prof_mask = 0;
+  int tag_gemm = DSM_PROF_OTHER, tag_attn = DSM_PROF_OTHER;
+  struct ProfRec {
+    int tag;
+    hipEvent_t a, b;
+  };
+  std::vector<ProfRec> prof_recs;
+  std::vector<hipEvent_t> prof_pool;
+  double prof_total_us[DSM_PROF_NTAGS] = {0};
+  uint64_t prof_launches[DSM_PROF_NTAGS] = {0};
+
+  hipEvent_t prof_event() {
+    if (!prof_pool.empty()) {
+      hipEvent_t ev = prof_pool.back();
+      prof_pool.pop_back();
+      return ev;
+    }
+    hipEvent_t ev = nullptr;
+    (void)hipEventCreate(&ev);
+    return ev;
+  }
+  // bracket one launch: returns an index to close with prof_end, or -1 when the class is not selected
+  int prof_begin(int tag, hipStream_t st) {
+    if (!(prof_mask & (1u << tag))) return -1;
+    ProfRec r{tag, prof_event(), prof_event()};
+    (void)hipEventRecord(r.a, st);
+    prof_recs.push_back(r);
+    return (int)prof_recs.size() - 1;
+  }
+  void prof_end(int h, hipStream_t st) {
+    if (h >= 0) (void)hipEventRecord(prof_recs[h].b, st);
+  }
 
   void set_error(const char* fmt, ...) {
     char buf[1024];
@@ -543,11 +576,13 @@ int launch_gemm_t(dsm_engine* e, hipStream_t st, GemmArgs& a, bool aligned) {
   size_t lds = S > 1 ? (size_t)S * NT * MT * 1024 : 0;
 #define DSM_LAUNCH(MTv, AL) \
   hipLaunchKernelGGL((gemm_mfma_kernel<WT, KVT, MTv, NT, EPI, AL>), grid, block, lds, st, a)
+  const int ph = e->prof_begin(e->tag_gemm, st);
   if (MT == 1) {
     if (aligned) DSM_LAUNCH(1, true); else DSM_LAUNCH(1, false);
   } else {
     if (aligned) DSM_LAUNCH(4, true); else DSM_LAUNCH(4, false);
   }
+  e->prof_end(ph, st);
 #undef DSM_LAUNCH
   HIPCHK(hipGetLastError());
   return 0;

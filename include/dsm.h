@@ -191,6 +191,18 @@ int dsm_asr_step_tokens_dev(dsm_engine*, const uint32_t* d_codes, const uint8_t*
                             uint32_t* d_text_tokens_out, float* d_vad_prs_out);
 /* Make the model stream wait for everything enqueued so far on the encoder stream. */
 int dsm_streams_join(dsm_engine*);
+/* step_pcm with device pointers: Mimi encode (model-side state) + LM step, all enqueued on the
+ * model stream, nothing synchronised.  d_codes_out / d_text_tokens_out / d_vad_prs_out may be NULL. */
+int dsm_asr_step_pcm_dev(dsm_engine*, const float* d_pcm, const uint8_t* d_mask, uint32_t* d_codes_out,
+                         uint32_t* d_text_tokens_out, float* d_vad_prs_out);
+
+/* Per-kernel-class device timing with HIP events recorded on the stream each kernel is launched on
+ * (feeds bench.py's roofline object).  tag_mask selects classes; dsm_prof_read synchronises, adds
+ * up the elapsed time of every bracketed launch since the last read, and resets. */
+enum { DSM_PROF_ATTN_LM = 0, DSM_PROF_GEMM_LM = 1, DSM_PROF_ATTN_MIMI = 2, DSM_PROF_GEMM_MIMI = 3,
+       DSM_PROF_RVQ = 4, DSM_PROF_OTHER = 5, DSM_PROF_NTAGS = 6 };
+int dsm_prof_enable(dsm_engine*, unsigned tag_mask);
+int dsm_prof_read(dsm_engine*, double* total_us /*[DSM_PROF_NTAGS]*/, uint64_t* launches /*[DSM_PROF_NTAGS]*/);
 
 /* Debug taps for the parity tests: copy a named intermediate of the last step to the host.
  * Names: "lm.hidden" [B,d], "lm.logits" [B,V], "mimi.seanet_out" [B,T,dim], "mimi.latent" [B,dim] ...

@@ -1509,3 +1509,12 @@ int orc_debug_read(orc_asr* a, const char* name, float* out, size_t cap) {
   memcpy(out, src, sizeof(float) * n);
   return (int)n;
 }
+
+/* ---- thin exports of the shared math (tests compare them with libm) ---- */
+float orc_expf(float x) { return dsm_expf(x); }
+float orc_elu(float x) { return dsm_elu(x); }
+float orc_silu(float x) { return dsm_silu(x); }
+float orc_gelu_erf(float x) { return dsm_gelu_erf(x); }
+void orc_sincosf(float x, float* s, float* c) { dsm_sincosf(x, s, c); }
+uint16_t orc_f32_to_bf16(float x) { return dsm_f32_to_bf16(x); }
+float orc_bf16_to_f32(uint16_t h) { return dsm_bf16_to_f32(h); }

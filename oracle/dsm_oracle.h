@@ -82,3 +82,17 @@ void orc_convtr1d_reset_batch_idx(orc_convtr1d*, int b);
 }
 #endif
 #endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+float orc_expf(float x);
+float orc_elu(float x);
+float orc_silu(float x);
+float orc_gelu_erf(float x);
+void orc_sincosf(float x, float* s, float* c);
+uint16_t orc_f32_to_bf16(float x);
+float orc_bf16_to_f32(uint16_t h);
+#ifdef __cplusplus
+}
+#endif

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/tiny_asr.json: outputs of the CPU oracle on the tiny configuration with seeded
+synthetic weights / PCM, a mixed mask schedule and slot resets.  The reference (Rust + Candle) cannot be
+run offline and ships no golden model outputs, so these vectors pin the ORACLE (against drift) and the
+HIP engine (against the oracle); they do not pin either against Candle ("parity unpinned")."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+STEPS, B = 24, 4
+RESETS = {7: [1], 15: [0, 2]}
+
+
+def schedule():
+    rng = np.random.default_rng(11)
+    m = (rng.random((STEPS, B)) < 0.75).astype(np.uint8)
+    m[:, 3] = 1
+    return m
+
+
+def run(make_engine, mimi_reset):
+    import dsm_amd
+    from dsm_amd import synth
+    cfg = dsm_amd.config_tiny()
+    lm, mimi = synth.make_synth_weights(cfg, os.environ.get("DSM_WEIGHTS_DIR", "/tmp/dsm_weights"), tag="tiny")
+    eng = make_engine(cfg, B, lm, mimi)
+    pcm = synth.synth_pcm(B, STEPS)
+    masks = schedule()
+    out = {"steps": STEPS, "batch": B, "resets": {str(k): v for k, v in RESETS.items()}, "masks": masks.tolist(),
+           "codes": [], "text": [], "prs_bits": [], "msgs": []}
+    for s in range(STEPS):
+        for slot in RESETS.get(s, []):
+            eng.reset_batch_idx(slot)
+            mimi_reset(eng, slot)
+        codes = eng.encode_step(pcm[s], masks[s])
+        act = masks[s].astype(bool)
+        codes = np.where(act[:, None], codes, 0)  # inactive slots: unspecified -> zeroed before they are fed back
+        text, prs = eng.step_tokens(codes, masks[s])
+        out["codes"].append(codes.tolist())
+        out["text"].append(np.where(act, text, 0).tolist())
+        out["prs_bits"].append(np.where(act[None, :], prs.view(np.uint32), 0).tolist())
+        out["msgs"].append([list(m) for m in eng.poll_msgs()])
+    return out
+
+
+if __name__ == "__main__":
+    import oracle
+    res = run(oracle.OracleAsr, lambda e, slot: e.mimi_reset_batch_idx(slot, side=0))
+    path = os.path.join(ROOT, "tests", "golden", "tiny_asr.json")
+    with open(path, "w") as f:
+        json.dump(res, f, separators=(",", ":"))
+    print("wrote", path, os.path.getsize(path), "bytes")
