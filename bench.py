@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="stream slots per GPU")
     ap.add_argument("--config", default="stt-1b-en_fr", choices=["stt-1b-en_fr", "stt-2.6b-en", "tiny"])
     ap.add_argument("--no-fill", action="store_true", help="skip the untimed ring-cache fill (debug only)")
+    ap.add_argument("--fast-fill", action="store_true",
+                    help="profiling aid: jump the ring positions to steady state instead of running `context` fill steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--weights-dir", default=os.environ.get("DSM_WEIGHTS_DIR", "/tmp/dsm_weights"))
@@ -131,7 +133,9 @@ def main():
         torch.cuda.synchronize()
 
     it = 0
-    if not args.no_fill:
+    if args.fast_fill:
+        eng.debug_set_positions(4 * ctx, 4 * cfg.mimi.transformer.context)
+    elif not args.no_fill:
         for _ in range(ctx):
             step(it)
             it += 1

@@ -69,6 +69,7 @@ ABI_SYMBOLS = [
     "dsm_asr_step_pcm", "dsm_asr_poll_msgs", "dsm_asr_reset_slot", "dsm_mimi_reset_slot", "dsm_sync",
     "dsm_get_metrics", "dsm_batch_size", "dsm_n_q", "dsm_mimi_encode_step_dev", "dsm_asr_step_tokens_dev",
     "dsm_streams_join", "dsm_debug_read", "dsm_asr_step_pcm_dev", "dsm_prof_enable", "dsm_prof_read",
+    "dsm_debug_set_positions",
 ]
 PROF_TAGS = ["attn_lm", "gemm_lm", "attn_mimi", "gemm_mimi", "rvq", "other"]
 
@@ -111,6 +112,8 @@ def load_library(path=None):
     lib.dsm_streams_join.argtypes = [vp]
     lib.dsm_debug_read.argtypes = [vp, C.c_char_p, fp, C.c_size_t]
     lib.dsm_asr_step_pcm_dev.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.dsm_debug_set_positions.argtypes = [vp, C.c_uint32, C.c_uint32]
+    lib.dsm_debug_set_positions.restype = C.c_int
     lib.dsm_prof_enable.argtypes = [vp, C.c_uint]
     lib.dsm_prof_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     for name in ("dsm_mimi_encode_step", "dsm_asr_step_tokens", "dsm_asr_step_pcm", "dsm_asr_poll_msgs",
@@ -284,6 +287,9 @@ class AsrEngine:
 
     def step_pcm_dev(self, d_pcm, d_mask, d_codes=None, d_text=None, d_prs=None):
         self._check(self.lib.dsm_asr_step_pcm_dev(self.h, d_pcm, d_mask, d_codes, d_text, d_prs))
+
+    def debug_set_positions(self, lm_pos, mimi_pos):
+        self._check(self.lib.dsm_debug_set_positions(self.h, lm_pos, mimi_pos))
 
     def prof_enable(self, tags):
         mask = 0

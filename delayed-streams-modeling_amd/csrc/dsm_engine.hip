@@ -564,21 +564,35 @@ int alloc_mimi_state(dsm_engine* e, MimiState* s, const MimiW& w, int B) {
 // ----------------------------------------------------------------------------------------------
 template <typename WT, typename KVT, int EPI, int NT>
 int launch_gemm_t(dsm_engine* e, hipStream_t st, GemmArgs& a, bool aligned) {
-  const int S = (a.Kpad + DSM_KC - 1) / DSM_KC;
-  if (S > 16) {
-    e->set_error("GEMM K=%d needs more than 16 K-chunks", a.K);
+  const int chunks = (a.Kpad + DSM_KC - 1) / DSM_KC;
+  const int rounds = (chunks + 15) / 16;          // chunks per wave when there are more than 16
+  const int S = (chunks + rounds - 1) / rounds;   // waves per workgroup
+  const int tiles16 = (a.N + 15) / 16;  // for the gate a.N is the hidden width: one (gate, up) tile pair per block
+  const int nx = (EPI == EPI_GATE) ? tiles16 : (tiles16 + NT - 1) / NT;
+  // M-tiles per wave: as many as possible (weights are re-read once per m-group) while the grid still covers
+  // the 256 CUs at least twice and the chunk partials fit in LDS
+  int MT = (NT == 2) ? 2 : 4;  // NT=2 x MT=4 would need > 128 VGPRs (spills under the 1024-thread cap)
+  while (MT > 1 && (a.M <= 16 * (MT / 2) || (long)nx * ((a.M + 16 * MT - 1) / (16 * MT)) * S < 2048 ||
+                    (chunks > 1 && (size_t)chunks * NT * MT * 1024 > 64 * 1024)))
+    MT /= 2;
+  if (chunks > 1 && (size_t)chunks * NT * MT * 1024 > 160 * 1024) {
+    e->set_error("GEMM K=%d: chunk partials do not fit in LDS", a.K);
     return DSM_ERR_INVALID;
   }
-  const int MT = a.M <= 16 ? 1 : 4;
-  const int tiles16 = (a.N + 15) / 16;  // for the gate a.N is the hidden width: one (gate, up) tile pair per block
-  dim3 grid((EPI == EPI_GATE) ? tiles16 : (tiles16 + NT - 1) / NT, (a.M + 16 * MT - 1) / (16 * MT));
+  // 16-byte epilogue accesses need every row offset to be a multiple of 4 floats
+  auto ok4 = [](const RowMap& m) { return m.ld % 4 == 0 && m.bstride % 4 == 0; };
+  a.vec = (a.N % 4 == 0) && (!a.Y || ok4(a.ymap)) && (!a.Y2 || ok4(a.y2map)) && (!a.res || ok4(a.rmap));
+  aligned = aligned && (a.K % 32 == 0);  // the fast kernel has no K-tail handling
+  dim3 grid(nx, (a.M + 16 * MT - 1) / (16 * MT));
   dim3 block(64 * S);
-  size_t lds = S > 1 ? (size_t)S * NT * MT * 1024 : 0;
+  size_t lds = chunks > 1 ? (size_t)chunks * NT * MT * 1024 : 0;
 #define DSM_LAUNCH(MTv, AL) \
   hipLaunchKernelGGL((gemm_mfma_kernel<WT, KVT, MTv, NT, EPI, AL>), grid, block, lds, st, a)
   const int ph = e->prof_begin(e->tag_gemm, st);
   if (MT == 1) {
     if (aligned) DSM_LAUNCH(1, true); else DSM_LAUNCH(1, false);
+  } else if (MT == 2) {
+    if (aligned) DSM_LAUNCH(2, true); else DSM_LAUNCH(2, false);
   } else {
     if (aligned) DSM_LAUNCH(4, true); else DSM_LAUNCH(4, false);
   }

@@ -53,6 +53,7 @@ struct GemmArgs {
   float* Y2;  // optional ELU(y) copy
   RowMap y2map;
   int act;  // 0 none, 1 gelu_erf (applied right after bias)
+  int vec;  // 1: every row offset of Y / Y2 / res is a multiple of 4 floats and N % 4 == 0 -> 16-byte accesses
   // EPI_QKV
   int d, hd, H, T, ctx;
   void* kcache;
@@ -85,6 +86,20 @@ __device__ __forceinline__ void load_w8<float>(const float* p, float (&o)[8]) {
 __device__ __forceinline__ void store_kv(uint16_t* p, float v) { *p = dsm_f32_to_bf16(v); }
 __device__ __forceinline__ void store_kv(float* p, float v) { *p = v; }
 
+__device__ __forceinline__ void store_kv4(uint16_t* p, const float (&o)[4]) {
+  uint2 v;
+  v.x = (uint32_t)dsm_f32_to_bf16(o[0]) | ((uint32_t)dsm_f32_to_bf16(o[1]) << 16);
+  v.y = (uint32_t)dsm_f32_to_bf16(o[2]) | ((uint32_t)dsm_f32_to_bf16(o[3]) << 16);
+  *reinterpret_cast<uint2*>(p) = v;
+}
+__device__ __forceinline__ void store_kv4(float* p, const float (&o)[4]) {
+  *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// One workgroup = S waves; the K range is cut into chunks of DSM_KC; wave w accumulates chunks w, w+S, ...
+// (one fmaf chain per chunk, in MFMA order) and parks each chunk's partial tile in LDS; the partials are then
+// summed left to right.  Operand fetch is register double-buffered: the loads of K-block i+1 are in flight
+// while the 8*NT*MT MFMAs of block i issue.
 template <typename WT, typename KVT, int MT, int NT, int EPI, bool XALIGNED>
 __global__ void gemm_mfma_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds_part[];
@@ -93,6 +108,7 @@ __global__ void gemm_mfma_kernel(GemmArgs a) {
   const int m_base = blockIdx.y * (16 * MT);
   const int n_base = blockIdx.x * ((EPI == EPI_GATE) ? 16 : 16 * NT);
   const WT* W = reinterpret_cast<const WT*>(a.W);
+  constexpr int TILES = NT * MT;
 
   const WT* wrow[NT];
 #pragma unroll
@@ -105,92 +121,109 @@ __global__ void gemm_mfma_kernel(GemmArgs a) {
     xrow[mt] = a.X + a.xmap.off(m) + 8 * q;
   }
   f32x4 acc[NT][MT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int chunks = (a.Kpad + DSM_KC - 1) / DSM_KC;
 
-  const int k0 = wave * DSM_KC;
-  const int k1 = min(k0 + DSM_KC, a.Kpad);
-  for (int kb = k0; kb < k1; kb += 32) {
-    float wa[NT][8], xb[MT][8];
+// XALIGNED (fast path): K % 32 == 0 and every X row is 16-byte aligned -> unconditional vector loads only, so
+// the compiler can keep the next block's loads in flight behind the MFMAs.  Otherwise: guarded scalar loads.
+#define DSM_LOAD_BLK(WA, XB, KB)                                                                   \
+  {                                                                                                \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) load_w8<WT>(wrow[nt] + (KB), WA[nt]);        \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                            \
+      if (XALIGNED) {                                                                              \
+        load_w8<float>(xrow[mt] + (KB), XB[mt]);                                                   \
+      } else {                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j)                                              \
+            XB[mt][j] = ((KB) + 8 * q + j < a.K) ? xrow[mt][(KB) + j] : 0.0f;                      \
+      }                                                                                            \
+    }                                                                                              \
+  }
+#define DSM_MFMA_BLK(WA, XB)                                                                       \
+  {                                                                                                \
+    _Pragma("unroll") for (int s = 0; s < 8; ++s)                                                  \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                              \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                              \
+        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(WA[nt][s], XB[mt][s], acc[nt][mt], 0, 0, 0); \
+  }
+
+  for (int c = wave; c < chunks; c += S) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) load_w8<WT>(wrow[nt] + kb, wa[nt]);
-    const bool tail = (kb + 32 > a.K);  // wave-uniform: only the very last block of an odd K
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      if (XALIGNED && !tail) {
-        load_w8<float>(xrow[mt] + kb, xb[mt]);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) xb[mt][j] = (kb + 8 * q + j < a.K) ? xrow[mt][kb + j] : 0.0f;
-      }
+      for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int k0 = c * DSM_KC;
+    const int k1 = min(k0 + DSM_KC, a.Kpad);
+    float wa0[NT][8], xb0[MT][8], wa1[NT][8], xb1[MT][8];
+    int kb = k0;
+    DSM_LOAD_BLK(wa0, xb0, kb);
+    for (;;) {
+      int kn = kb + 32;
+      bool more = kn < k1;
+      if (more) DSM_LOAD_BLK(wa1, xb1, kn);
+      DSM_MFMA_BLK(wa0, xb0);
+      if (!more) break;
+      kb = kn;
+      kn = kb + 32;
+      more = kn < k1;
+      if (more) DSM_LOAD_BLK(wa0, xb0, kn);
+      DSM_MFMA_BLK(wa1, xb1);
+      if (!more) break;
+      kb = kn;
     }
-#pragma unroll
-    for (int s = 0; s < 8; ++s)
+    if (chunks > 1) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
-          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nt][s], xb[mt][s], acc[nt][mt], 0, 0, 0);
+          *reinterpret_cast<f32x4*>(&lds_part[(((c * TILES) + nt * MT + mt) * 64 + lane) * 4]) = acc[nt][mt];
+    }
   }
+#undef DSM_LOAD_BLK
+#undef DSM_MFMA_BLK
 
   // ---- split-K combine: ((c0 + c1) + c2) + ... through LDS ----
-  constexpr int TILES = NT * MT;
-  if (S > 1) {
+  // GATE / RVQ epilogues need all NT tiles of one m-tile in the same wave: wave w' owns m-tiles w', w'+S, ...;
+  // otherwise tile (nt, mt) is owned by wave (nt*MT + mt) % S.
+  if (chunks > 1) {
+    __syncthreads();
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-        *reinterpret_cast<f32x4*>(&lds_part[(((wave * TILES) + nt * MT + mt) * 64 + lane) * 4]) = acc[nt][mt];
-    __syncthreads();
-    if (EPI == EPI_GATE || EPI == EPI_RVQ) {
-      // these epilogues need all NT tiles of one m-tile in the same wave: wave w' takes m-tiles w', w'+S, ...
-#pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        if ((mt % S) != wave) continue;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          f32x4 tot = *reinterpret_cast<f32x4*>(&lds_part[((nt * MT + mt) * 64 + lane) * 4]);
-          for (int w = 1; w < S; ++w) {
-            f32x4 p = *reinterpret_cast<f32x4*>(&lds_part[(((w * TILES) + nt * MT + mt) * 64 + lane) * 4]);
-            tot = tot + p;
-          }
-          acc[nt][mt] = tot;
+        const int owner = (EPI == EPI_GATE || EPI == EPI_RVQ) ? (mt % S) : ((nt * MT + mt) % S);
+        if (owner != wave) continue;
+        f32x4 tot = *reinterpret_cast<f32x4*>(&lds_part[((nt * MT + mt) * 64 + lane) * 4]);
+        for (int c = 1; c < chunks; ++c) {
+          f32x4 p = *reinterpret_cast<f32x4*>(&lds_part[(((c * TILES) + nt * MT + mt) * 64 + lane) * 4]);
+          tot = tot + p;
         }
+        acc[nt][mt] = tot;
       }
-    } else {
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          if (((nt * MT + mt) % S) != wave) continue;
-          f32x4 tot = *reinterpret_cast<f32x4*>(&lds_part[((nt * MT + mt) * 64 + lane) * 4]);
-          for (int w = 1; w < S; ++w) {
-            f32x4 p = *reinterpret_cast<f32x4*>(&lds_part[(((w * TILES) + nt * MT + mt) * 64 + lane) * 4]);
-            tot = tot + p;
-          }
-          acc[nt][mt] = tot;
-        }
-    }
   }
+  const bool multi = chunks > 1;
 
   // ---- epilogue: lane holds rows n = n_tile + 4q + i (i = 0..3) of column m = m_tile + r ----
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int m = m_base + 16 * mt + r;
     if (EPI == EPI_GATE) {
-      if (S > 1 && (mt % S) != wave) continue;
+      if (multi && (mt % S) != wave) continue;
       if (m >= a.M) continue;
       const int n = n_base + 4 * q;
-      float* y = a.Y + a.ymap.off(m) + n;
+      float o[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (n + i < a.N) y[i] = dsm_silu(acc[0][mt][i]) * acc[NT - 1][mt][i];
+      for (int i = 0; i < 4; ++i) o[i] = dsm_silu(acc[0][mt][i]) * acc[NT - 1][mt][i];
+      float* y = a.Y + a.ymap.off(m) + n;
+      if (a.vec && n + 3 < a.N) {
+        *reinterpret_cast<float4*>(y) = make_float4(o[0], o[1], o[2], o[3]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (n + i < a.N) y[i] = o[i];
+      }
       continue;
     }
     if (EPI == EPI_RVQ) {
-      if (S > 1 && (mt % S) != wave) continue;
+      if (multi && (mt % S) != wave) continue;
       // dist = c2[n] - dot; argmin over the tile's 16*NT rows, first occurrence on ties
       float bv = DSM_INF_F;
       uint32_t bi = 0xFFFFFFFFu;
@@ -216,11 +249,12 @@ __global__ void gemm_mfma_kernel(GemmArgs a) {
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      if (S > 1 && ((nt * MT + mt) % S) != wave) continue;
+      if (multi && ((nt * MT + mt) % S) != wave) continue;
       if (m >= a.M) continue;
       const int n = n_base + nt * a.nt_stride + 4 * q;
       if (n >= a.N) continue;
       f32x4 v = acc[nt][mt];
+      const bool full = a.vec && (n + 3 < a.N);
       if (EPI == EPI_STORE) {
         float o[4];
 #pragma unroll
@@ -235,21 +269,34 @@ __global__ void gemm_mfma_kernel(GemmArgs a) {
         }
         if (a.res) {
           const float* rp = a.res + a.rmap.off(m) + n;
+          if (full) {
+            float4 rv = *reinterpret_cast<const float4*>(rp);
+            o[0] = rv.x + o[0]; o[1] = rv.y + o[1]; o[2] = rv.z + o[2]; o[3] = rv.w + o[3];
+          } else {
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (n + i < a.N) o[i] = rp[i] + o[i];
+            for (int i = 0; i < 4; ++i)
+              if (n + i < a.N) o[i] = rp[i] + o[i];
+          }
         }
         if (a.Y) {
           float* y = a.Y + a.ymap.off(m) + n;
+          if (full) {
+            *reinterpret_cast<float4*>(y) = make_float4(o[0], o[1], o[2], o[3]);
+          } else {
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (n + i < a.N) y[i] = o[i];
+            for (int i = 0; i < 4; ++i)
+              if (n + i < a.N) y[i] = o[i];
+          }
         }
         if (a.Y2) {
           float* y2 = a.Y2 + a.y2map.off(m) + n;
+          if (full) {
+            *reinterpret_cast<float4*>(y2) = make_float4(dsm_elu(o[0]), dsm_elu(o[1]), dsm_elu(o[2]), dsm_elu(o[3]));
+          } else {
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (n + i < a.N) y2[i] = dsm_elu(o[i]);
+            for (int i = 0; i < 4; ++i)
+              if (n + i < a.N) y2[i] = dsm_elu(o[i]);
+          }
         }
       } else if (EPI == EPI_QKV) {
         // n in [0, 3d): part 0 = q, 1 = k, 2 = v; (b,t,3,H,hd) layout — core/batched_transformer.rs:77-82
@@ -257,25 +304,21 @@ __global__ void gemm_mfma_kernel(GemmArgs a) {
         const int b = m / a.T;
         float o[4] = {v[0], v[1], v[2], v[3]};
         if (part < 2 && a.rope_cs) {  // rope_i on interleaved pairs — core/transformer.rs:373-377
-          const float* cs = a.rope_cs + ((long)m * (a.hd / 2) + (i0 >> 1)) * 2;
+          const float4 cs = *reinterpret_cast<const float4*>(a.rope_cs + ((long)m * (a.hd / 2) + (i0 >> 1)) * 2);
+          const float co[2] = {cs.x, cs.z}, si[2] = {cs.y, cs.w};
 #pragma unroll
           for (int p = 0; p < 2; ++p) {
-            float co = cs[2 * p], si = cs[2 * p + 1];
             float x0 = v[2 * p], x1 = v[2 * p + 1];
-            float t0 = x0 * co, t1 = x1 * si, t2 = x0 * si, t3 = x1 * co;
+            float t0 = x0 * co[p], t1 = x1 * si[p], t2 = x0 * si[p], t3 = x1 * co[p];
             o[2 * p] = t0 - t1;
             o[2 * p + 1] = t2 + t3;
           }
         }
         if (part == 0) {
-          float* y = a.Y + (long)m * a.d + c;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) y[i] = o[i];
+          *reinterpret_cast<float4*>(a.Y + (long)m * a.d + c) = make_float4(o[0], o[1], o[2], o[3]);
         } else if (a.active[b]) {  // inactive slots: the reference scatters garbage that is never read
           KVT* cache = reinterpret_cast<KVT*>(part == 1 ? a.kcache : a.vcache);
-          KVT* dst = cache + (((long)b * a.H + h) * a.ctx + a.widx[m]) * a.hd + i0;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) store_kv(dst + i, o[i]);
+          store_kv4(cache + (((long)b * a.H + h) * a.ctx + a.widx[m]) * a.hd + i0, o);
         }
       }
     }
@@ -286,35 +329,54 @@ __global__ void gemm_mfma_kernel(GemmArgs a) {
 // Row norms — one wave per row.  mode 1: RmsNorm (core/batched_transformer.rs:194-198),
 // mode 0: LayerNorm (core/batched_transformer.rs:200-222).
 // ------------------------------------------------------------------------------------------
+// One wave per row; lane l owns elements 256*it + 4*l + j (it < d/256 <= 8) and keeps them in registers,
+// so x is read once.  Reduction order = dsm_numerics.h "row reductions".
 __global__ void row_norm_kernel(float* __restrict__ y, const float* __restrict__ x, const float* __restrict__ w,
                                 const float* __restrict__ b, int rows, int d, float eps, int rms) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= rows) return;
   const float* xr = x + (long)row * d;
+  float4 v[8];
   float s = 0.0f, s2 = 0.0f;
-  for (int it = 0; it * 256 < d; ++it) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int i = it * 256 + 4 * lane + j;
-      if (i < d) {
-        float v = xr[i];
-        s = s + v;
-        s2 = DSM_FMAF(v, v, s2);
-      }
+  for (int it = 0; it < 8; ++it) {
+    const int i = it * 256 + 4 * lane;
+    v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < d) {  // d % 4 == 0: a lane's four elements are in range together
+      v[it] = *reinterpret_cast<const float4*>(xr + i);
+      s = s + v[it].x; s2 = DSM_FMAF(v[it].x, v[it].x, s2);
+      s = s + v[it].y; s2 = DSM_FMAF(v[it].y, v[it].y, s2);
+      s = s + v[it].z; s2 = DSM_FMAF(v[it].z, v[it].z, s2);
+      s = s + v[it].w; s2 = DSM_FMAF(v[it].w, v[it].w, s2);
     }
   }
   s2 = wave_sum64(s2);
   float* yr = y + (long)row * d;
+  float m = 1.f, mean = 0.f, inv = 0.f;
   if (rms) {
-    float m = sqrtf(s2 / (float)d + eps);
-    for (int i = lane; i < d; i += 64) yr[i] = (xr[i] / m) * w[i];
+    m = sqrtf(s2 / (float)d + eps);
   } else {
     s = wave_sum64(s);
-    float mean = s / (float)d;
+    mean = s / (float)d;
     float var = s2 / (float)d - mean * mean;
-    float inv = 1.0f / sqrtf(var + eps);
-    for (int i = lane; i < d; i += 64) yr[i] = ((xr[i] - mean) * inv) * w[i] + b[i];
+    inv = 1.0f / sqrtf(var + eps);
+  }
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int i = it * 256 + 4 * lane;
+    if (i < d) {
+      const float4 wv = *reinterpret_cast<const float4*>(w + i);
+      float4 o;
+      if (rms) {
+        o.x = (v[it].x / m) * wv.x; o.y = (v[it].y / m) * wv.y; o.z = (v[it].z / m) * wv.z; o.w = (v[it].w / m) * wv.w;
+      } else {
+        const float4 bv = *reinterpret_cast<const float4*>(b + i);
+        o.x = ((v[it].x - mean) * inv) * wv.x + bv.x; o.y = ((v[it].y - mean) * inv) * wv.y + bv.y;
+        o.z = ((v[it].z - mean) * inv) * wv.z + bv.z; o.w = ((v[it].w - mean) * inv) * wv.w + bv.w;
+      }
+      *reinterpret_cast<float4*>(yr + i) = o;
+    }
   }
 }
 
@@ -356,29 +418,31 @@ __global__ __launch_bounds__(256) void attn_kernel(float* __restrict__ out, cons
   const KVT* Kb = kcache + ((long)b * H + h) * ctx * HD;
   const KVT* Vb = vcache + ((long)b * H + h) * ctx * HD;
 
-  // ---- phase 1: scores ----
-  for (int j0 = wave * G; j0 < nvalid; j0 += NW * G) {
-    const int j = j0 + g;
-    if (j < nvalid) {
-      float kv[8];
-      load_w8<KVT>(Kb + (long)j * HD + 8 * li, kv);
-      const long delta = (e1 - j) % ctx;
+  // ---- phase 1: scores.  UNR independent 16-byte K loads in flight per lane; out-of-range keys are
+  // clamped to the last valid row (loaded, never used) so that the loads need no branches ----
+  constexpr int UNR = 4;
+  const int jlast = nvalid - 1;
+  const int last_slot = (int)(e1 % ctx);  // ring slot holding the newest key
+  for (int j0 = wave * G; j0 < nvalid; j0 += UNR * NW * G) {
+    float kv[UNR][8];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int j = min(j0 + u * NW * G + g, jlast);
+      load_w8<KVT>(Kb + (long)j * HD + 8 * li, kv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int j = j0 + u * NW * G + g;
+      int delta = last_slot - min(j, jlast);  // == (e1 - j) mod ctx without a 64-bit division
+      delta += (delta < 0) ? ctx : 0;
 #pragma unroll
       for (int t = 0; t < T; ++t) {
         float p = 0.0f;
 #pragma unroll
-        for (int dd = 0; dd < 8; ++dd) p = DSM_FMAF(qv[t][dd], kv[dd], p);
+        for (int dd = 0; dd < 8; ++dd) p = DSM_FMAF(qv[t][dd], kv[u][dd], p);
 #pragma unroll
         for (int off = LPK / 2; off >= 1; off >>= 1) p = p + __shfl_xor(p, off, 64);
-        if (li == 0) sc[t * ctx + j] = (delta >= (long)(T - 1 - t)) ? p * scale : -DSM_INF_F;
-      }
-    } else {
-      // keep the shuffles convergent for partially filled last iterations
-#pragma unroll
-      for (int t = 0; t < T; ++t) {
-        float p = 0.0f;
-#pragma unroll
-        for (int off = LPK / 2; off >= 1; off >>= 1) p = p + __shfl_xor(p, off, 64);
+        if (li == 0 && j < nvalid) sc[t * ctx + j] = (delta >= T - 1 - t) ? p * scale : -DSM_INF_F;
       }
     }
   }
@@ -415,16 +479,22 @@ __global__ __launch_bounds__(256) void attn_kernel(float* __restrict__ out, cons
   for (int t = 0; t < T; ++t)
 #pragma unroll
     for (int dd = 0; dd < 8; ++dd) acc[t][dd] = 0.0f;
-  for (int j0 = wave * G; j0 < nvalid; j0 += NW * G) {
-    const int j = j0 + g;
-    if (j < nvalid) {
-      float vv[8];
-      load_w8<KVT>(Vb + (long)j * HD + 8 * li, vv);
+  for (int j0 = wave * G; j0 < nvalid; j0 += UNR * NW * G) {
+    float vv[UNR][8];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int j = min(j0 + u * NW * G + g, jlast);
+      load_w8<KVT>(Vb + (long)j * HD + 8 * li, vv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {  // ascending j per (wave, group): the canonical accumulation order
+      const int j = j0 + u * NW * G + g;
 #pragma unroll
       for (int t = 0; t < T; ++t) {
-        float wgt = sc[t * ctx + j] / lsum[t];
+        // out-of-range keys get weight 0: fmaf(0, v, acc) == acc for the finite v of the clamped row
+        const float wgt = (j < nvalid) ? sc[t * ctx + j] / lsum[t] : 0.0f;
 #pragma unroll
-        for (int dd = 0; dd < 8; ++dd) acc[t][dd] = DSM_FMAF(wgt, vv[dd], acc[t][dd]);
+        for (int dd = 0; dd < 8; ++dd) acc[t][dd] = DSM_FMAF(wgt, vv[u][dd], acc[t][dd]);
       }
     }
   }

@@ -139,7 +139,7 @@ DSM_HD void dsm_sincosf(float xf, float* s_out, float* c_out) {
  * 32 (fmaf(0,0,acc) == acc).  Chunk partial sums are then added left to right:
  * ((c0 + c1) + c2) + ...  and the bias / residual are added last.
  * --------------------------------------------------------------------------------- */
-#define DSM_KC 512
+#define DSM_KC 256
 
 /* WAVE SUM: 64 lane partials combined by an xor butterfly, offsets 32,16,8,4,2,1
  * (== __shfl_xor all-reduce).  In-place; every entry ends up holding the total. */

@@ -204,6 +204,10 @@ enum { DSM_PROF_ATTN_LM = 0, DSM_PROF_GEMM_LM = 1, DSM_PROF_ATTN_MIMI = 2, DSM_P
 int dsm_prof_enable(dsm_engine*, unsigned tag_mask);
 int dsm_prof_read(dsm_engine*, double* total_us /*[DSM_PROF_NTAGS]*/, uint64_t* launches /*[DSM_PROF_NTAGS]*/);
 
+/* Profiling aid: pretend every slot already streamed `pos` frames (ring index = pos mod ctx, cache content
+ * untouched) so that short profiler runs see steady-state attention traffic.  Never used for `value`. */
+int dsm_debug_set_positions(dsm_engine*, uint32_t lm_pos, uint32_t mimi_pos);
+
 /* Debug taps for the parity tests: copy a named intermediate of the last step to the host.
  * Names: "lm.hidden" [B,d], "lm.logits" [B,V], "mimi.seanet_out" [B,T,dim], "mimi.latent" [B,dim] ...
  * Returns the number of floats written, or <0. */
