@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--no-fill", action="store_true", help="skip the untimed ring-cache fill (debug only)")
     ap.add_argument("--fast-fill", action="store_true",
                     help="profiling aid: jump the ring positions to steady state instead of running `context` fill steps")
+    ap.add_argument("--no-overlap", action="store_true", help="single-stream step_pcm instead of the encoder/model stream pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--weights-dir", default=os.environ.get("DSM_WEIGHTS_DIR", "/tmp/dsm_weights"))
@@ -125,7 +126,13 @@ def main():
     codes = torch.zeros(B * cfg.audio_codebooks, dtype=torch.int32, device=dev)
 
     def step(i):
-        eng.step_pcm_dev(pcm[i % n_pcm].data_ptr(), mask.data_ptr(), codes.data_ptr(), text.data_ptr(), prs.data_ptr())
+        if args.no_overlap:  # everything on one stream (asr::State::step_pcm)
+            eng.step_pcm_dev(pcm[i % n_pcm].data_ptr(), mask.data_ptr(), codes.data_ptr(), text.data_ptr(), prs.data_ptr())
+        else:
+            # the reference's two-thread pipeline (srv/batched_asr.rs:314-522): Mimi encode on the encoder stream, LM
+            # step on the model stream; encode of frame i+1 overlaps the LM step of frame i, codes handed over on-device
+            eng.encode_step_dev(pcm[i % n_pcm].data_ptr(), mask.data_ptr(), codes.data_ptr())
+            eng.step_tokens_dev(None, mask.data_ptr(), text.data_ptr(), prs.data_ptr())
 
     def barrier():
         if world > 1:
@@ -161,14 +168,20 @@ def main():
     dt = float(dt_t.item())
     ms_per_step = dt / args.steps * 1000.0
 
-    # per-class device time of one extra pass (not part of `value`): where a step goes
+    # one extra single-stream pass (not part of `value`): per-class device time of a step, and the dominant kernel
+    # timed without a concurrent stream competing for HBM
+    overlap = not args.no_overlap
+    args.no_overlap = True
+    torch.cuda.synchronize()
     eng.prof_enable(dsm_amd.PROF_TAGS)
     eng.prof_read()
     for _ in range(5):
         step(it)
         it += 1
-    breakdown = {k: round(v[0] / 5.0, 1) for k, v in eng.prof_read().items()}
+    iso = eng.prof_read()
+    breakdown = {k: round(v[0] / 5.0, 1) for k, v in iso.items()}
     eng.prof_enable([])
+    args.no_overlap = not overlap
 
     if rank == 0:
         H, hd, L = cfg.lm.num_heads, cfg.lm.d_model // cfg.lm.num_heads, cfg.lm.num_layers
@@ -190,12 +203,16 @@ def main():
             "config": {"workload": "%s batch=%d streaming, ring KV cache full (%d frames), Mimi encode + LM decode HIP path"
                                    % (args.config, B, fill),
                        "streams_per_gpu": B, "parallelism": "replicas x%d (independent stream batches)" % world,
+                       "streams": "single stream" if args.no_overlap else "encoder stream || model stream (as the reference's two threads)",
                        "weights_broadcast_ms": bcast_ms},
             "roofline": {"bound": "hbm", "kernel": "attn_kernel<bf16,hd%d,T1> (LM ring-cache attention, %d launches/step)" % (hd, L),
                          "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "algorithmic_bytes_per_launch": attn_bytes, "avg_launch_us": attn_avg_us,
-                         "launches_timed": int(attn_n), "traffic": None},
-            "step_breakdown_us": breakdown,
+                         "launches_timed": int(attn_n), "traffic": None,
+                         "isolated_single_stream": {"avg_launch_us": iso["attn_lm"][0] / max(iso["attn_lm"][1], 1),
+                                                    "achieved": attn_bytes / (iso["attn_lm"][0] / max(iso["attn_lm"][1], 1) * 1e-6) / 1e9,
+                                                    "frac": attn_bytes / (iso["attn_lm"][0] / max(iso["attn_lm"][1], 1) * 1e-6) / 1e9 / 8000.0}},
+            "step_breakdown_us_single_stream": breakdown,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, B, lm_path, mimi_path, args.cpu_steps)

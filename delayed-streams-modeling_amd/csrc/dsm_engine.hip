@@ -139,6 +139,8 @@ struct dsm_engine {
   dsm_asr_config cfg{};
   int B = 0, device = 0;
   hipStream_t s_enc = nullptr, s_model = nullptr;
+  hipEvent_t ev_codes_consumed = nullptr;
+  bool codes_consumed_valid = false;
   hipEvent_t ev_join = nullptr, ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;
   MimiW mimi_w;
   MimiState mimi[2];
@@ -157,6 +159,9 @@ struct dsm_engine {
   std::vector<dsm_asr_msg> msgs;
   std::vector<uint32_t> msg_tokens;
   dsm_metrics metrics{};
+  // split-K workspaces of the tiled GEMM, one per stream (0 = encoder, 1 = model); grown on first use
+  float* gemm_ws[2] = {nullptr, nullptr};
+  size_t gemm_ws_cap[2] = {0, 0};
   // per-kernel-class event timing (dsm_prof_*)
   unsigned prof_mask = 0;
   int tag_gemm = DSM_PROF_OTHER, tag_attn = DSM_PROF_OTHER;
@@ -258,7 +263,7 @@ int round_up(int x, int m) { return (x + m - 1) / m * m; }
 int pack_linear(dsm_engine* e, Linear* L, const float* w, int N, int K, bool bf16, const float* bias) {
   L->N = N;
   L->K = K;
-  L->Npad = round_up(N, 32);
+  L->Npad = round_up(N, 64) + 64;  // the tiled kernel reads whole 64-row tiles (and the gate's up-tile at +hidden)
   L->Kpad = round_up(K, 32);
   L->bf16 = bf16;
   size_t n = (size_t)L->Npad * L->Kpad;
@@ -563,7 +568,50 @@ int alloc_mimi_state(dsm_engine* e, MimiState* s, const MimiW& w, int B) {
 // GEMM launch
 // ----------------------------------------------------------------------------------------------
 template <typename WT, typename KVT, int EPI, int NT>
+int launch_gemm_tiled(dsm_engine* e, hipStream_t st, GemmArgs& a) {
+  const int chunks = (a.Kpad + DSM_KC - 1) / DSM_KC;
+  const int gx = (a.N + 63) / 64;
+  int MT = a.M > 32 ? 4 : (a.M > 16 ? 2 : 1);
+  while (MT > 1 && (long)gx * chunks * ((a.M + 16 * MT - 1) / (16 * MT)) < 256) MT /= 2;  // cover the 256 CUs
+  auto ok4 = [](const RowMap& m) { return m.ld % 4 == 0 && m.bstride % 4 == 0; };
+  a.vec = (a.N % 4 == 0) && (!a.Y || ok4(a.ymap)) && (!a.Y2 || ok4(a.y2map)) && (!a.res || ok4(a.rmap));
+  a.ws_ntiles = (((NT - 1) * a.nt_stride) >> 4) + gx * 4;
+  const int mtiles = (a.M + 15) / 16;
+  if (chunks > 1) {
+    const int wsid = (st == e->s_enc) ? 0 : 1;
+    size_t need = (size_t)chunks * mtiles * a.ws_ntiles * 256 * sizeof(float);
+    if (need > e->gemm_ws_cap[wsid]) {  // first use of a bigger shape: grow (never happens in steady state)
+      HIPCHK(hipStreamSynchronize(st));
+      if (e->gemm_ws[wsid]) HIPCHK(hipFree(e->gemm_ws[wsid]));
+      e->gemm_ws[wsid] = nullptr;
+      e->gemm_ws_cap[wsid] = 0;
+      void* p = nullptr;
+      HIPCHK(hipMalloc(&p, need));
+      e->gemm_ws[wsid] = reinterpret_cast<float*>(p);
+      e->gemm_ws_cap[wsid] = need;
+    }
+    a.ws = e->gemm_ws[wsid];
+  }
+  dim3 grid(gx, chunks, (a.M + 16 * MT - 1) / (16 * MT));
+  const int ph = e->prof_begin(e->tag_gemm, st);
+  if (MT == 4)
+    hipLaunchKernelGGL((gemm_tile_kernel<WT, KVT, 4, NT, EPI>), grid, dim3(256), 0, st, a);
+  else if (MT == 2)
+    hipLaunchKernelGGL((gemm_tile_kernel<WT, KVT, 2, NT, EPI>), grid, dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((gemm_tile_kernel<WT, KVT, 1, NT, EPI>), grid, dim3(256), 0, st, a);
+  if (chunks > 1) {
+    const int out_tiles = mtiles * ((a.N + 15) / 16);
+    hipLaunchKernelGGL((gemm_reduce_kernel<KVT, EPI>), dim3((out_tiles + 3) / 4), dim3(256), 0, st, a, chunks);
+  }
+  e->prof_end(ph, st);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+template <typename WT, typename KVT, int EPI, int NT>
 int launch_gemm_t(dsm_engine* e, hipStream_t st, GemmArgs& a, bool aligned) {
+  if (aligned && a.K % 32 == 0) return launch_gemm_tiled<WT, KVT, EPI, NT>(e, st, a);
   const int chunks = (a.Kpad + DSM_KC - 1) / DSM_KC;
   const int rounds = (chunks + 15) / 16;          // chunks per wave when there are more than 16
   const int S = (chunks + rounds - 1) / rounds;   // waves per workgroup

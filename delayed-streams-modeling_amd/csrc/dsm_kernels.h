@@ -64,6 +64,9 @@ struct GemmArgs {
   // EPI_RVQ
   float* pval;     // [n_tiles][M]
   uint32_t* pidx;  // [n_tiles][M]
+  // split-K workspace of the tiled kernel: [chunks][m-tiles][ws_ntiles][64 lanes] f32x4
+  float* ws;
+  int ws_ntiles;
 };
 
 template <typename WT>
@@ -96,10 +99,120 @@ __device__ __forceinline__ void store_kv4(float* p, const float (&o)[4]) {
   *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
-// One workgroup = S waves; the K range is cut into chunks of DSM_KC; wave w accumulates chunks w, w+S, ...
-// (one fmaf chain per chunk, in MFMA order) and parks each chunk's partial tile in LDS; the partials are then
-// summed left to right.  Operand fetch is register double-buffered: the loads of K-block i+1 are in flight
-// while the 8*NT*MT MFMAs of block i issue.
+// ---- epilogues (shared by the three GEMM kernels).  A lane holds rows n..n+3 of column m of a 16x16 tile. ----
+template <typename KVT, int EPI>
+__device__ __forceinline__ void epi_store_qkv(const GemmArgs& a, f32x4 v, int m, int n) {
+  if (m >= a.M || n >= a.N) return;
+  const bool full = a.vec && (n + 3 < a.N);
+  if (EPI == EPI_STORE) {
+    float o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float t = v[i];
+      if (n + i < a.N) {
+        if (a.bias) t = t + a.bias[n + i];
+        if (a.act == 1) t = dsm_gelu_erf(t);
+        if (a.scale) t = t * a.scale[n + i];
+      }
+      o[i] = t;
+    }
+    if (a.res) {
+      const float* rp = a.res + a.rmap.off(m) + n;
+      if (full) {
+        float4 rv = *reinterpret_cast<const float4*>(rp);
+        o[0] = rv.x + o[0]; o[1] = rv.y + o[1]; o[2] = rv.z + o[2]; o[3] = rv.w + o[3];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (n + i < a.N) o[i] = rp[i] + o[i];
+      }
+    }
+    if (a.Y) {
+      float* y = a.Y + a.ymap.off(m) + n;
+      if (full) {
+        *reinterpret_cast<float4*>(y) = make_float4(o[0], o[1], o[2], o[3]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (n + i < a.N) y[i] = o[i];
+      }
+    }
+    if (a.Y2) {
+      float* y2 = a.Y2 + a.y2map.off(m) + n;
+      if (full) {
+        *reinterpret_cast<float4*>(y2) = make_float4(dsm_elu(o[0]), dsm_elu(o[1]), dsm_elu(o[2]), dsm_elu(o[3]));
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (n + i < a.N) y2[i] = dsm_elu(o[i]);
+      }
+    }
+  } else {  // EPI_QKV
+    // n in [0, 3d): part 0 = q, 1 = k, 2 = v; (b,t,3,H,hd) layout — core/batched_transformer.rs:77-82
+    const int part = n / a.d, c = n - part * a.d, h = c / a.hd, i0 = c - h * a.hd;
+    const int b = m / a.T;
+    float o[4] = {v[0], v[1], v[2], v[3]};
+    if (part < 2 && a.rope_cs) {  // rope_i on interleaved pairs — core/transformer.rs:373-377
+      const float4 cs = *reinterpret_cast<const float4*>(a.rope_cs + ((long)m * (a.hd / 2) + (i0 >> 1)) * 2);
+      const float co[2] = {cs.x, cs.z}, si[2] = {cs.y, cs.w};
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        float x0 = v[2 * p], x1 = v[2 * p + 1];
+        float t0 = x0 * co[p], t1 = x1 * si[p], t2 = x0 * si[p], t3 = x1 * co[p];
+        o[2 * p] = t0 - t1;
+        o[2 * p + 1] = t2 + t3;
+      }
+    }
+    if (part == 0) {
+      *reinterpret_cast<float4*>(a.Y + (long)m * a.d + c) = make_float4(o[0], o[1], o[2], o[3]);
+    } else if (a.active[b]) {  // inactive slots: the reference scatters garbage that is never read
+      KVT* cache = reinterpret_cast<KVT*>(part == 1 ? a.kcache : a.vcache);
+      store_kv4(cache + (((long)b * a.H + h) * a.ctx + a.widx[m]) * a.hd + i0, o);
+    }
+  }
+}
+
+// Mlp::Gating — core/batched_transformer.rs:170-176: silu(first half) * second half
+__device__ __forceinline__ void epi_gate(const GemmArgs& a, f32x4 g, f32x4 u, int m, int n) {
+  if (m >= a.M || n >= a.N) return;
+  float o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = dsm_silu(g[i]) * u[i];
+  float* y = a.Y + a.ymap.off(m) + n;
+  if (a.vec && n + 3 < a.N) {
+    *reinterpret_cast<float4*>(y) = make_float4(o[0], o[1], o[2], o[3]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (n + i < a.N) y[i] = o[i];
+  }
+}
+
+// EuclideanCodebook::encode_slow — core/quantization.rs:122-131: dist = c2 - dot, argmin over the 16 codebook
+// rows of this tile (first occurrence on ties); all 64 lanes of the wave must call it.
+__device__ __forceinline__ void epi_rvq(const GemmArgs& a, f32x4 v, int m, int n, int tile16, int q) {
+  float bv = DSM_INF_F;
+  uint32_t bi = 0xFFFFFFFFu;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float dist = a.bias[n + i] - v[i];
+    if (n + i < a.N && (dist < bv || (dist == bv && (uint32_t)(n + i) < bi))) { bv = dist; bi = (uint32_t)(n + i); }
+  }
+#pragma unroll
+  for (int off = 16; off <= 32; off <<= 1) {
+    float ov = __shfl_xor(bv, off, 64);
+    uint32_t oi = __shfl_xor(bi, off, 64);
+    if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  if (q == 0 && m < a.M) {
+    a.pval[(long)tile16 * a.M + m] = bv;
+    a.pidx[(long)tile16 * a.M + m] = bi;
+  }
+}
+
+// ---- generic GEMM (any K, any X alignment): one workgroup = S waves, wave w accumulates K-chunks w, w+S, ...
+// and parks each chunk's partial tile in LDS; the partials are summed left to right.  Used for the few layers
+// the tiled kernel below cannot take (K % 32 != 0 or unaligned rows: the 1-channel input conv, tiny test models).
 template <typename WT, typename KVT, int MT, int NT, int EPI, bool XALIGNED>
 __global__ void gemm_mfma_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds_part[];
@@ -123,28 +236,6 @@ __global__ void gemm_mfma_kernel(GemmArgs a) {
   f32x4 acc[NT][MT];
   const int chunks = (a.Kpad + DSM_KC - 1) / DSM_KC;
 
-// XALIGNED (fast path): K % 32 == 0 and every X row is 16-byte aligned -> unconditional vector loads only, so
-// the compiler can keep the next block's loads in flight behind the MFMAs.  Otherwise: guarded scalar loads.
-#define DSM_LOAD_BLK(WA, XB, KB)                                                                   \
-  {                                                                                                \
-    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) load_w8<WT>(wrow[nt] + (KB), WA[nt]);        \
-    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                            \
-      if (XALIGNED) {                                                                              \
-        load_w8<float>(xrow[mt] + (KB), XB[mt]);                                                   \
-      } else {                                                                                     \
-        _Pragma("unroll") for (int j = 0; j < 8; ++j)                                              \
-            XB[mt][j] = ((KB) + 8 * q + j < a.K) ? xrow[mt][(KB) + j] : 0.0f;                      \
-      }                                                                                            \
-    }                                                                                              \
-  }
-#define DSM_MFMA_BLK(WA, XB)                                                                       \
-  {                                                                                                \
-    _Pragma("unroll") for (int s = 0; s < 8; ++s)                                                  \
-    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                              \
-    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                              \
-        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(WA[nt][s], XB[mt][s], acc[nt][mt], 0, 0, 0); \
-  }
-
   for (int c = wave; c < chunks; c += S) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -152,22 +243,26 @@ __global__ void gemm_mfma_kernel(GemmArgs a) {
       for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int k0 = c * DSM_KC;
     const int k1 = min(k0 + DSM_KC, a.Kpad);
-    float wa0[NT][8], xb0[MT][8], wa1[NT][8], xb1[MT][8];
-    int kb = k0;
-    DSM_LOAD_BLK(wa0, xb0, kb);
-    for (;;) {
-      int kn = kb + 32;
-      bool more = kn < k1;
-      if (more) DSM_LOAD_BLK(wa1, xb1, kn);
-      DSM_MFMA_BLK(wa0, xb0);
-      if (!more) break;
-      kb = kn;
-      kn = kb + 32;
-      more = kn < k1;
-      if (more) DSM_LOAD_BLK(wa0, xb0, kn);
-      DSM_MFMA_BLK(wa1, xb1);
-      if (!more) break;
-      kb = kn;
+    for (int kb = k0; kb < k1; kb += 32) {
+      float wa[NT][8], xb[MT][8];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) load_w8<WT>(wrow[nt] + kb, wa[nt]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        if (XALIGNED) {
+          load_w8<float>(xrow[mt] + kb, xb[mt]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) xb[mt][j] = (kb + 8 * q + j < a.K) ? xrow[mt][kb + j] : 0.0f;
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nt][s], xb[mt][s], acc[nt][mt], 0, 0, 0);
     }
     if (chunks > 1) {
 #pragma unroll
@@ -177,19 +272,16 @@ __global__ void gemm_mfma_kernel(GemmArgs a) {
           *reinterpret_cast<f32x4*>(&lds_part[(((c * TILES) + nt * MT + mt) * 64 + lane) * 4]) = acc[nt][mt];
     }
   }
-#undef DSM_LOAD_BLK
-#undef DSM_MFMA_BLK
-
-  // ---- split-K combine: ((c0 + c1) + c2) + ... through LDS ----
-  // GATE / RVQ epilogues need all NT tiles of one m-tile in the same wave: wave w' owns m-tiles w', w'+S, ...;
-  // otherwise tile (nt, mt) is owned by wave (nt*MT + mt) % S.
-  if (chunks > 1) {
+  // split-K combine ((c0 + c1) + c2) + ...  GATE needs both tiles of an m-tile in one wave: wave w' owns
+  // m-tiles w', w'+S, ...; otherwise tile (nt, mt) is owned by wave (nt*MT + mt) % S.
+  const bool multi = chunks > 1;
+  if (multi) {
     __syncthreads();
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        const int owner = (EPI == EPI_GATE || EPI == EPI_RVQ) ? (mt % S) : ((nt * MT + mt) % S);
+        const int owner = (EPI == EPI_GATE) ? (mt % S) : ((nt * MT + mt) % S);
         if (owner != wave) continue;
         f32x4 tot = *reinterpret_cast<f32x4*>(&lds_part[((nt * MT + mt) * 64 + lane) * 4]);
         for (int c = 1; c < chunks; ++c) {
@@ -199,130 +291,173 @@ __global__ void gemm_mfma_kernel(GemmArgs a) {
         acc[nt][mt] = tot;
       }
   }
-  const bool multi = chunks > 1;
-
-  // ---- epilogue: lane holds rows n = n_tile + 4q + i (i = 0..3) of column m = m_tile + r ----
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int m = m_base + 16 * mt + r;
     if (EPI == EPI_GATE) {
       if (multi && (mt % S) != wave) continue;
-      if (m >= a.M) continue;
-      const int n = n_base + 4 * q;
-      float o[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = dsm_silu(acc[0][mt][i]) * acc[NT - 1][mt][i];
-      float* y = a.Y + a.ymap.off(m) + n;
-      if (a.vec && n + 3 < a.N) {
-        *reinterpret_cast<float4*>(y) = make_float4(o[0], o[1], o[2], o[3]);
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (n + i < a.N) y[i] = o[i];
-      }
-      continue;
-    }
-    if (EPI == EPI_RVQ) {
-      if (multi && (mt % S) != wave) continue;
-      // dist = c2[n] - dot; argmin over the tile's 16*NT rows, first occurrence on ties
-      float bv = DSM_INF_F;
-      uint32_t bi = 0xFFFFFFFFu;
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          int n = n_base + nt * a.nt_stride + 4 * q + i;
-          float dist = a.bias[n] - acc[nt][mt][i];
-          if (n < a.N && (dist < bv || (dist == bv && (uint32_t)n < bi))) { bv = dist; bi = (uint32_t)n; }
-        }
-#pragma unroll
-      for (int off = 16; off <= 32; off <<= 1) {
-        float ov = __shfl_xor(bv, off, 64);
-        uint32_t oi = __shfl_xor(bi, off, 64);
-        if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-      }
-      if (q == 0 && m < a.M) {
-        a.pval[(long)blockIdx.x * a.M + m] = bv;
-        a.pidx[(long)blockIdx.x * a.M + m] = bi;
-      }
+      epi_gate(a, acc[0][mt], acc[NT - 1][mt], m, n_base + 4 * q);
       continue;
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      if (multi && ((nt * MT + mt) % S) != wave) continue;
-      if (m >= a.M) continue;
+      if (multi && ((nt * MT + mt) % S) != wave) continue;  // wave-uniform
       const int n = n_base + nt * a.nt_stride + 4 * q;
-      if (n >= a.N) continue;
-      f32x4 v = acc[nt][mt];
-      const bool full = a.vec && (n + 3 < a.N);
-      if (EPI == EPI_STORE) {
-        float o[4];
+      if (EPI == EPI_RVQ)
+        epi_rvq(a, acc[nt][mt], m, n, (n_base + nt * a.nt_stride) >> 4, q);
+      else
+        epi_store_qkv<KVT, EPI>(a, acc[nt][mt], m, n);
+    }
+  }
+}
+
+// ---- tiled GEMM (fast path: K % 32 == 0, 16-byte aligned X rows).
+// Workgroup = 4 waves; tile = 64 weight rows (wave w owns 16-row n-tile w; for the gate also the matching
+// "up" tile at +nt_stride) x 16*MT activation rows x ONE K-chunk (blockIdx.y).  The 32-wide activation block
+// [16*MT][32] f32 is fetched once per workgroup with coalesced full-line loads, staged in LDS (rows padded to
+// 36 floats: conflict-free ds_read_b128 fragments) and shared by the four waves; weights stream straight to
+// registers.  Loads of block i+1 are in flight behind the MFMAs of block i (double-buffered LDS, one barrier
+// per block).  chunks == 1: fused epilogue.  chunks > 1: the chunk's partial tiles go to a workspace slab in
+// MFMA register layout and gemm_reduce_kernel sums the slabs left to right (canonical order) and runs the epilogue.
+#define DSM_XS_LD 36
+template <typename WT, typename KVT, int MT, int NT, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) float Xs[2][16 * MT][DSM_XS_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int chunk = blockIdx.y, chunks = gridDim.y;
+  const int m_base = blockIdx.z * (16 * MT);
+  const int n_base = blockIdx.x * 64 + 16 * wave;  // this wave's n-tile
+  const WT* W = reinterpret_cast<const WT*>(a.W);
+  const int k0 = chunk * DSM_KC;
+  const int k1 = min(k0 + DSM_KC, a.Kpad);
+
+  const WT* wrow[NT];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float t = v[i];
-          if (n + i < a.N) {
-            if (a.bias) t = t + a.bias[n + i];
-            if (a.act == 1) t = dsm_gelu_erf(t);
-            if (a.scale) t = t * a.scale[n + i];
-          }
-          o[i] = t;
-        }
-        if (a.res) {
-          const float* rp = a.res + a.rmap.off(m) + n;
-          if (full) {
-            float4 rv = *reinterpret_cast<const float4*>(rp);
-            o[0] = rv.x + o[0]; o[1] = rv.y + o[1]; o[2] = rv.z + o[2]; o[3] = rv.w + o[3];
-          } else {
+  for (int nt = 0; nt < NT; ++nt) wrow[nt] = W + (long)(n_base + nt * a.nt_stride + r) * a.Kpad + 8 * q;
+  // cooperative X fetch: 16*MT rows x 8 float4 pieces; thread t takes piece t (and t+256 when MT == 4).
+  // Scalars, not arrays: small per-thread arrays ended up in scratch memory here.
+  constexpr int PIECES = 16 * MT * 8;
+  constexpr bool TWO = PIECES > 256;
+  const bool has0 = tid < PIECES;
+  const int row0 = has0 ? (tid >> 3) : 0, part = tid & 7;
+  int m0 = m_base + row0;
+  m0 = m0 < a.M ? m0 : a.M - 1;
+  const float* xsrc0 = a.X + a.xmap.off(m0) + 4 * part;
+  const int xdst0 = row0 * DSM_XS_LD + 4 * part;
+  int m1 = m_base + row0 + 32;
+  m1 = m1 < a.M ? m1 : a.M - 1;
+  const float* xsrc1 = a.X + a.xmap.off(m1) + 4 * part;
+  const int xdst1 = (row0 + 32) * DSM_XS_LD + 4 * part;
+
+  f32x4 acc[NT][MT];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-              if (n + i < a.N) o[i] = rp[i] + o[i];
-          }
-        }
-        if (a.Y) {
-          float* y = a.Y + a.ymap.off(m) + n;
-          if (full) {
-            *reinterpret_cast<float4*>(y) = make_float4(o[0], o[1], o[2], o[3]);
-          } else {
+  for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-              if (n + i < a.N) y[i] = o[i];
-          }
-        }
-        if (a.Y2) {
-          float* y2 = a.Y2 + a.y2map.off(m) + n;
-          if (full) {
-            *reinterpret_cast<float4*>(y2) = make_float4(dsm_elu(o[0]), dsm_elu(o[1]), dsm_elu(o[2]), dsm_elu(o[3]));
-          } else {
+    for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float4 xg0 = make_float4(0.f, 0.f, 0.f, 0.f), xg1 = xg0;
+  float wa[NT][8], wn[NT][8];
+  if (has0) xg0 = *reinterpret_cast<const float4*>(xsrc0 + k0);
+  if (TWO) xg1 = *reinterpret_cast<const float4*>(xsrc1 + k0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-              if (n + i < a.N) y2[i] = dsm_elu(o[i]);
-          }
-        }
-      } else if (EPI == EPI_QKV) {
-        // n in [0, 3d): part 0 = q, 1 = k, 2 = v; (b,t,3,H,hd) layout — core/batched_transformer.rs:77-82
-        const int part = n / a.d, c = n - part * a.d, h = c / a.hd, i0 = c - h * a.hd;
-        const int b = m / a.T;
-        float o[4] = {v[0], v[1], v[2], v[3]};
-        if (part < 2 && a.rope_cs) {  // rope_i on interleaved pairs — core/transformer.rs:373-377
-          const float4 cs = *reinterpret_cast<const float4*>(a.rope_cs + ((long)m * (a.hd / 2) + (i0 >> 1)) * 2);
-          const float co[2] = {cs.x, cs.z}, si[2] = {cs.y, cs.w};
+  for (int nt = 0; nt < NT; ++nt) load_w8<WT>(wrow[nt] + k0, wn[nt]);
+  int buf = 0;
+  for (int kb = k0; kb < k1; kb += 32) {
+    float* xs = &Xs[buf][0][0];
+    if (has0) *reinterpret_cast<float4*>(xs + xdst0) = xg0;
+    if (TWO) *reinterpret_cast<float4*>(xs + xdst1) = xg1;
 #pragma unroll
-          for (int p = 0; p < 2; ++p) {
-            float x0 = v[2 * p], x1 = v[2 * p + 1];
-            float t0 = x0 * co[p], t1 = x1 * si[p], t2 = x0 * si[p], t3 = x1 * co[p];
-            o[2 * p] = t0 - t1;
-            o[2 * p + 1] = t2 + t3;
-          }
-        }
-        if (part == 0) {
-          *reinterpret_cast<float4*>(a.Y + (long)m * a.d + c) = make_float4(o[0], o[1], o[2], o[3]);
-        } else if (a.active[b]) {  // inactive slots: the reference scatters garbage that is never read
-          KVT* cache = reinterpret_cast<KVT*>(part == 1 ? a.kcache : a.vcache);
-          store_kv4(cache + (((long)b * a.H + h) * a.ctx + a.widx[m]) * a.hd + i0, o);
-        }
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wa[nt][j] = wn[nt][j];
+    __syncthreads();
+    const int kn = kb + 32;
+    if (kn < k1) {
+      if (has0) xg0 = *reinterpret_cast<const float4*>(xsrc0 + kn);
+      if (TWO) xg1 = *reinterpret_cast<const float4*>(xsrc1 + kn);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) load_w8<WT>(wrow[nt] + kn, wn[nt]);
+    }
+    float xb[MT][8];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const float* fp = xs + (16 * mt + r) * DSM_XS_LD + 8 * q;
+      float4 f0 = *reinterpret_cast<const float4*>(fp), f1 = *reinterpret_cast<const float4*>(fp + 4);
+      xb[mt][0] = f0.x; xb[mt][1] = f0.y; xb[mt][2] = f0.z; xb[mt][3] = f0.w;
+      xb[mt][4] = f1.x; xb[mt][5] = f1.y; xb[mt][6] = f1.z; xb[mt][7] = f1.w;
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nt][s], xb[mt][s], acc[nt][mt], 0, 0, 0);
+    buf ^= 1;
+  }
+
+  if (chunks > 1) {
+    // slab[chunk][m-tile][n-tile16][lane] f32x4 — coalesced 16-byte stores, read back the same way
+    const int mtiles = (a.M + 15) >> 4, ntiles = a.ws_ntiles;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int mtile = (m_base >> 4) + mt;
+      if (mtile >= mtiles) continue;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int ntile = (n_base + nt * a.nt_stride) >> 4;
+        *reinterpret_cast<f32x4*>(a.ws + ((((long)chunk * mtiles + mtile) * ntiles + ntile) * 64 + lane) * 4) = acc[nt][mt];
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m_base + 16 * mt + r;
+    if (EPI == EPI_GATE) {
+      epi_gate(a, acc[0][mt], acc[NT - 1][mt], m, n_base + 4 * q);
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n = n_base + nt * a.nt_stride + 4 * q;
+        if (EPI == EPI_RVQ)
+          epi_rvq(a, acc[nt][mt], m, n, (n_base + nt * a.nt_stride) >> 4, q);
+        else
+          epi_store_qkv<KVT, EPI>(a, acc[nt][mt], m, n);
       }
     }
   }
+}
+
+// Ordered split-K reduce + epilogue: one wave per 16x16 output tile (a gate/up tile pair for EPI_GATE).
+template <typename KVT, int EPI>
+__global__ __launch_bounds__(256) void gemm_reduce_kernel(GemmArgs a, int chunks) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int mtiles = (a.M + 15) >> 4, ntiles = a.ws_ntiles;
+  const int out_ntiles = (a.N + 15) >> 4;  // gate: a.N is the hidden width
+  const int t = blockIdx.x * 4 + wave;
+  if (t >= mtiles * out_ntiles) return;
+  const int mtile = t / out_ntiles, ntile = t % out_ntiles;
+  constexpr int NT = (EPI == EPI_GATE) ? 2 : 1;
+  f32x4 tot[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int nti = ntile + nt * (a.nt_stride >> 4);
+    const float* p = a.ws + (((long)mtile * ntiles + nti) * 64 + lane) * 4;
+    const long cstride = (long)mtiles * ntiles * 256;
+    f32x4 v = *reinterpret_cast<const f32x4*>(p);
+    for (int c = 1; c < chunks; ++c) v = v + *reinterpret_cast<const f32x4*>(p + c * cstride);
+    tot[nt] = v;
+  }
+  const int m = mtile * 16 + r, n = ntile * 16 + 4 * q;
+  if (EPI == EPI_GATE)
+    epi_gate(a, tot[0], tot[NT - 1], m, n);
+  else if (EPI == EPI_RVQ)
+    epi_rvq(a, tot[0], m, n, ntile, q);
+  else
+    epi_store_qkv<KVT, EPI>(a, tot[0], m, n);
 }
 
 // ------------------------------------------------------------------------------------------
