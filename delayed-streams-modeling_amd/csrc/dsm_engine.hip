@@ -600,12 +600,22 @@ int launch_gemm_tiled(dsm_engine* e, hipStream_t st, GemmArgs& a) {
     hipLaunchKernelGGL((gemm_tile_kernel<WT, KVT, 2, NT, EPI>), grid, dim3(256), 0, st, a);
   else
     hipLaunchKernelGGL((gemm_tile_kernel<WT, KVT, 1, NT, EPI>), grid, dim3(256), 0, st, a);
+  const bool rows_ok = (EPI == EPI_STORE) && a.norm_out && a.vec && !a.Y2 && a.Y && a.N <= 4096 && a.ymap.bstride == 0;
   if (chunks > 1) {
-    const int out_tiles = mtiles * ((a.N + 15) / 16);
-    hipLaunchKernelGGL((gemm_reduce_kernel<KVT, EPI>), dim3((out_tiles + 3) / 4), dim3(256), 0, st, a, chunks);
+    if (rows_ok) {
+      hipLaunchKernelGGL(gemm_reduce_rows_kernel, dim3(a.M), dim3(256), 0, st, a, chunks);
+    } else {
+      const int out_tiles = mtiles * ((a.N + 15) / 16);
+      hipLaunchKernelGGL((gemm_reduce_kernel<KVT, EPI>), dim3((out_tiles + 3) / 4), dim3(256), 0, st, a, chunks);
+    }
   }
   e->prof_end(ph, st);
   HIPCHK(hipGetLastError());
+  if (a.norm_out && !(chunks > 1 && rows_ok)) {  // the norm could not be fused: run it on the stored rows
+    hipLaunchKernelGGL(row_norm_kernel, dim3(a.M), dim3(256), 0, st, a.norm_out, a.Y, a.norm_w, a.norm_b, a.M,
+                       a.N, a.norm_eps, a.norm_rms);
+    HIPCHK(hipGetLastError());
+  }
   return 0;
 }
 
@@ -647,6 +657,11 @@ int launch_gemm_t(dsm_engine* e, hipStream_t st, GemmArgs& a, bool aligned) {
   e->prof_end(ph, st);
 #undef DSM_LAUNCH
   HIPCHK(hipGetLastError());
+  if (a.norm_out) {
+    hipLaunchKernelGGL(row_norm_kernel, dim3(a.M), dim3(256), 0, st, a.norm_out, a.Y, a.norm_w, a.norm_b, a.M,
+                       a.N, a.norm_eps, a.norm_rms);
+    HIPCHK(hipGetLastError());
+  }
   return 0;
 }
 

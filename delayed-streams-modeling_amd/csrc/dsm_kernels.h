@@ -64,9 +64,15 @@ struct GemmArgs {
   // EPI_RVQ
   float* pval;     // [n_tiles][M]
   uint32_t* pidx;  // [n_tiles][M]
-  // split-K workspace of the tiled kernel: [chunks][m-tiles][ws_ntiles][64 lanes] f32x4
+  // split-K workspace of the tiled kernel: [chunks][M padded to 16][ws_ntiles*16] f32, row-major
   float* ws;
   int ws_ntiles;
+  // optional row norm fused behind an EPI_STORE GEMM whose N is d_model (gemm_reduce_rows_kernel)
+  const float* norm_w;
+  const float* norm_b;
+  float* norm_out;
+  float norm_eps;
+  int norm_rms;
 };
 
 template <typename WT>
@@ -356,58 +362,62 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs a) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  float4 xg0 = make_float4(0.f, 0.f, 0.f, 0.f), xg1 = xg0;
-  float wa[NT][8], wn[NT][8];
-  if (has0) xg0 = *reinterpret_cast<const float4*>(xsrc0 + k0);
-  if (TWO) xg1 = *reinterpret_cast<const float4*>(xsrc1 + k0);
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) load_w8<WT>(wrow[nt] + k0, wn[nt]);
-  int buf = 0;
-  for (int kb = k0; kb < k1; kb += 32) {
-    float* xs = &Xs[buf][0][0];
-    if (has0) *reinterpret_cast<float4*>(xs + xdst0) = xg0;
-    if (TWO) *reinterpret_cast<float4*>(xs + xdst1) = xg1;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) wa[nt][j] = wn[nt][j];
-    __syncthreads();
-    const int kn = kb + 32;
-    if (kn < k1) {
-      if (has0) xg0 = *reinterpret_cast<const float4*>(xsrc0 + kn);
-      if (TWO) xg1 = *reinterpret_cast<const float4*>(xsrc1 + kn);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) load_w8<WT>(wrow[nt] + kn, wn[nt]);
-    }
-    float xb[MT][8];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const float* fp = xs + (16 * mt + r) * DSM_XS_LD + 8 * q;
-      float4 f0 = *reinterpret_cast<const float4*>(fp), f1 = *reinterpret_cast<const float4*>(fp + 4);
-      xb[mt][0] = f0.x; xb[mt][1] = f0.y; xb[mt][2] = f0.z; xb[mt][3] = f0.w;
-      xb[mt][4] = f1.x; xb[mt][5] = f1.y; xb[mt][6] = f1.z; xb[mt][7] = f1.w;
-    }
-#pragma unroll
-    for (int s = 0; s < 8; ++s)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nt][s], xb[mt][s], acc[nt][mt], 0, 0, 0);
-    buf ^= 1;
+  // operand fetch runs TWO K-blocks ahead of the MFMAs (register sets A and B alternate): L2/HBM latency under
+  // load exceeds one block's worth of MFMAs (32 x 32 cycles)
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 xa0 = z4, xa1 = z4, xb0 = z4, xb1 = z4;
+  float wA[NT][8], wB[NT][8];
+#define DSM_FETCH(X0, X1, WR, KB)                                                       \
+  {                                                                                     \
+    if (has0) X0 = *reinterpret_cast<const float4*>(xsrc0 + (KB));                      \
+    if (TWO) X1 = *reinterpret_cast<const float4*>(xsrc1 + (KB));                       \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) load_w8<WT>(wrow[nt] + (KB), WR[nt]); \
   }
+#define DSM_STEP(X0, X1, WR, KB)                                                        \
+  {                                                                                     \
+    float* xs = &Xs[buf][0][0];                                                         \
+    if (has0) *reinterpret_cast<float4*>(xs + xdst0) = X0;                              \
+    if (TWO) *reinterpret_cast<float4*>(xs + xdst1) = X1;                               \
+    float wa[NT][8];                                                                    \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                   \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) wa[nt][j] = WR[nt][j];                \
+    __syncthreads();                                                                    \
+    if ((KB) + 64 < k1) DSM_FETCH(X0, X1, WR, (KB) + 64)                                \
+    float xb[MT][8];                                                                    \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                 \
+      const float* fp = xs + (16 * mt + r) * DSM_XS_LD + 8 * q;                         \
+      float4 f0 = *reinterpret_cast<const float4*>(fp), f1 = *reinterpret_cast<const float4*>(fp + 4); \
+      xb[mt][0] = f0.x; xb[mt][1] = f0.y; xb[mt][2] = f0.z; xb[mt][3] = f0.w;           \
+      xb[mt][4] = f1.x; xb[mt][5] = f1.y; xb[mt][6] = f1.z; xb[mt][7] = f1.w;           \
+    }                                                                                   \
+    _Pragma("unroll") for (int s = 0; s < 8; ++s)                                       \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                   \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                   \
+        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nt][s], xb[mt][s], acc[nt][mt], 0, 0, 0); \
+    buf ^= 1;                                                                           \
+  }
+  int buf = 0;
+  DSM_FETCH(xa0, xa1, wA, k0)
+  if (k0 + 32 < k1) DSM_FETCH(xb0, xb1, wB, k0 + 32)
+  for (int kb = k0; kb < k1; kb += 64) {
+    DSM_STEP(xa0, xa1, wA, kb)
+    if (kb + 32 < k1) DSM_STEP(xb0, xb1, wB, kb + 32)
+  }
+#undef DSM_FETCH
+#undef DSM_STEP
 
   if (chunks > 1) {
-    // slab[chunk][m-tile][n-tile16][lane] f32x4 — coalesced 16-byte stores, read back the same way
-    const int mtiles = (a.M + 15) >> 4, ntiles = a.ws_ntiles;
+    // slab[chunk][m][n] f32, row-major with ld = ws_ntiles*16: a lane stores its 4 consecutive n of row m
+    const long ld = (long)a.ws_ntiles * 16;
+    const long mpad = (long)((a.M + 15) >> 4) * 16;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const int mtile = (m_base >> 4) + mt;
-      if (mtile >= mtiles) continue;
+      const int m = m_base + 16 * mt + r;
+      if (m >= mpad) continue;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        const int ntile = (n_base + nt * a.nt_stride) >> 4;
-        *reinterpret_cast<f32x4*>(a.ws + ((((long)chunk * mtiles + mtile) * ntiles + ntile) * 64 + lane) * 4) = acc[nt][mt];
+        const int n = n_base + nt * a.nt_stride + 4 * q;
+        *reinterpret_cast<f32x4*>(a.ws + ((long)chunk * mpad + m) * ld + n) = acc[nt][mt];
       }
     }
     return;
@@ -435,23 +445,22 @@ template <typename KVT, int EPI>
 __global__ __launch_bounds__(256) void gemm_reduce_kernel(GemmArgs a, int chunks) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, q = lane >> 4;
-  const int mtiles = (a.M + 15) >> 4, ntiles = a.ws_ntiles;
+  const int mtiles = (a.M + 15) >> 4;
   const int out_ntiles = (a.N + 15) >> 4;  // gate: a.N is the hidden width
   const int t = blockIdx.x * 4 + wave;
   if (t >= mtiles * out_ntiles) return;
   const int mtile = t / out_ntiles, ntile = t % out_ntiles;
   constexpr int NT = (EPI == EPI_GATE) ? 2 : 1;
+  const long ld = (long)a.ws_ntiles * 16, cstride = (long)mtiles * 16 * ld;
+  const int m = mtile * 16 + r, n = ntile * 16 + 4 * q;
   f32x4 tot[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int nti = ntile + nt * (a.nt_stride >> 4);
-    const float* p = a.ws + (((long)mtile * ntiles + nti) * 64 + lane) * 4;
-    const long cstride = (long)mtiles * ntiles * 256;
+    const float* p = a.ws + (long)m * ld + n + nt * a.nt_stride;
     f32x4 v = *reinterpret_cast<const f32x4*>(p);
     for (int c = 1; c < chunks; ++c) v = v + *reinterpret_cast<const f32x4*>(p + c * cstride);
     tot[nt] = v;
   }
-  const int m = mtile * 16 + r, n = ntile * 16 + 4 * q;
   if (EPI == EPI_GATE)
     epi_gate(a, tot[0], tot[NT - 1], m, n);
   else if (EPI == EPI_RVQ)
@@ -460,25 +469,109 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(GemmArgs a, int chunks
     epi_store_qkv<KVT, EPI>(a, tot[0], m, n);
 }
 
-// ------------------------------------------------------------------------------------------
-// Row norms — one wave per row.  mode 1: RmsNorm (core/batched_transformer.rs:194-198),
-// mode 0: LayerNorm (core/batched_transformer.rs:200-222).
-// ------------------------------------------------------------------------------------------
-// One wave per row; lane l owns elements 256*it + 4*l + j (it < d/256 <= 8) and keeps them in registers,
-// so x is read once.  Reduction order = dsm_numerics.h "row reductions".
-__global__ void row_norm_kernel(float* __restrict__ y, const float* __restrict__ x, const float* __restrict__ w,
-                                const float* __restrict__ b, int rows, int d, float eps, int rms) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const float* xr = x + (long)row * d;
-  float4 v[8];
+// Canonical row reduction (dsm_numerics.h): 256 threads per row, thread t owns elements 1024*it + 4*t + j;
+// wave butterflies, then the 4 wave totals left to right.  `red` = 8 floats of LDS.
+__device__ __forceinline__ void block_row_sums(float& s, float& s2, float* red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  s = wave_sum64(s);
+  s2 = wave_sum64(s2);
+  if (lane == 0) { red[wave] = s; red[4 + wave] = s2; }
+  __syncthreads();
+  s = ((red[0] + red[1]) + red[2]) + red[3];
+  s2 = ((red[4] + red[5]) + red[6]) + red[7];
+}
+
+#define DSM_ROW_ITS 4  // d_model <= 4096
+
+__device__ __forceinline__ void row_norm_apply(const float4 (&v)[DSM_ROW_ITS], float s, float s2, int d, float eps, int rms,
+                                               const float* __restrict__ w, const float* __restrict__ b,
+                                               float* __restrict__ out) {
+  float mm = 1.f, mean = 0.f, inv = 0.f;
+  if (rms) {
+    mm = sqrtf(s2 / (float)d + eps);
+  } else {
+    mean = s / (float)d;
+    float var = s2 / (float)d - mean * mean;
+    inv = 1.0f / sqrtf(var + eps);
+  }
+#pragma unroll
+  for (int it = 0; it < DSM_ROW_ITS; ++it) {
+    const int i = it * 1024 + 4 * (int)threadIdx.x;
+    if (i < d) {
+      const float4 wv = *reinterpret_cast<const float4*>(w + i);
+      float4 o;
+      if (rms) {
+        o.x = (v[it].x / mm) * wv.x; o.y = (v[it].y / mm) * wv.y; o.z = (v[it].z / mm) * wv.z; o.w = (v[it].w / mm) * wv.w;
+      } else {
+        const float4 bv = *reinterpret_cast<const float4*>(b + i);
+        o.x = ((v[it].x - mean) * inv) * wv.x + bv.x; o.y = ((v[it].y - mean) * inv) * wv.y + bv.y;
+        o.z = ((v[it].z - mean) * inv) * wv.z + bv.z; o.w = ((v[it].w - mean) * inv) * wv.w + bv.w;
+      }
+      *reinterpret_cast<float4*>(out + i) = o;
+    }
+  }
+}
+
+// Ordered split-K reduce + STORE epilogue (bias / act / scale / residual) + the row norm that follows it, one
+// workgroup per output row (N = d_model).  Same per-element arithmetic as epi_store_qkv<EPI_STORE> followed by
+// row_norm_kernel.
+__global__ __launch_bounds__(256) void gemm_reduce_rows_kernel(GemmArgs a, int chunks) {
+  __shared__ float red[8];
+  const int m = blockIdx.x;
+  const int d = a.N;
+  const long ld = (long)a.ws_ntiles * 16, cstride = (long)((a.M + 15) >> 4) * 16 * ld;
+  const float* p = a.ws + (long)m * ld;
+  const float* rp = a.res ? a.res + a.rmap.off(m) : nullptr;
+  float* yp = a.Y + a.ymap.off(m);
+  float4 v[DSM_ROW_ITS];
   float s = 0.0f, s2 = 0.0f;
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int i = it * 256 + 4 * lane;
+  for (int it = 0; it < DSM_ROW_ITS; ++it) {
+    const int i = it * 1024 + 4 * (int)threadIdx.x;
     v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < d) {  // d % 4 == 0: a lane's four elements are in range together
+    if (i < d) {
+      f32x4 t = *reinterpret_cast<const f32x4*>(p + i);
+      for (int c = 1; c < chunks; ++c) t = t + *reinterpret_cast<const f32x4*>(p + c * cstride + i);
+      float o[4] = {t[0], t[1], t[2], t[3]};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (a.bias) o[j] = o[j] + a.bias[i + j];
+        if (a.act == 1) o[j] = dsm_gelu_erf(o[j]);
+        if (a.scale) o[j] = o[j] * a.scale[i + j];
+      }
+      if (rp) {
+        const float4 rv = *reinterpret_cast<const float4*>(rp + i);
+        o[0] = rv.x + o[0]; o[1] = rv.y + o[1]; o[2] = rv.z + o[2]; o[3] = rv.w + o[3];
+      }
+      v[it] = make_float4(o[0], o[1], o[2], o[3]);
+      *reinterpret_cast<float4*>(yp + i) = v[it];
+      s = s + o[0]; s2 = DSM_FMAF(o[0], o[0], s2);
+      s = s + o[1]; s2 = DSM_FMAF(o[1], o[1], s2);
+      s = s + o[2]; s2 = DSM_FMAF(o[2], o[2], s2);
+      s = s + o[3]; s2 = DSM_FMAF(o[3], o[3], s2);
+    }
+  }
+  block_row_sums(s, s2, red);
+  row_norm_apply(v, s, s2, d, a.norm_eps, a.norm_rms, a.norm_w, a.norm_b, a.norm_out + (long)m * d);
+}
+
+// ------------------------------------------------------------------------------------------
+// Row norms — one workgroup per row.  rms 1: RmsNorm (core/batched_transformer.rs:194-198),
+// rms 0: LayerNorm (core/batched_transformer.rs:200-222).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void row_norm_kernel(float* __restrict__ y, const float* __restrict__ x,
+                                                       const float* __restrict__ w, const float* __restrict__ b, int rows,
+                                                       int d, float eps, int rms) {
+  __shared__ float red[8];
+  const int row = blockIdx.x;
+  const float* xr = x + (long)row * d;
+  float4 v[DSM_ROW_ITS];
+  float s = 0.0f, s2 = 0.0f;
+#pragma unroll
+  for (int it = 0; it < DSM_ROW_ITS; ++it) {
+    const int i = it * 1024 + 4 * (int)threadIdx.x;
+    v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < d) {  // d % 4 == 0: a thread's four elements are in range together
       v[it] = *reinterpret_cast<const float4*>(xr + i);
       s = s + v[it].x; s2 = DSM_FMAF(v[it].x, v[it].x, s2);
       s = s + v[it].y; s2 = DSM_FMAF(v[it].y, v[it].y, s2);
@@ -486,33 +579,8 @@ __global__ void row_norm_kernel(float* __restrict__ y, const float* __restrict__
       s = s + v[it].w; s2 = DSM_FMAF(v[it].w, v[it].w, s2);
     }
   }
-  s2 = wave_sum64(s2);
-  float* yr = y + (long)row * d;
-  float m = 1.f, mean = 0.f, inv = 0.f;
-  if (rms) {
-    m = sqrtf(s2 / (float)d + eps);
-  } else {
-    s = wave_sum64(s);
-    mean = s / (float)d;
-    float var = s2 / (float)d - mean * mean;
-    inv = 1.0f / sqrtf(var + eps);
-  }
-#pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int i = it * 256 + 4 * lane;
-    if (i < d) {
-      const float4 wv = *reinterpret_cast<const float4*>(w + i);
-      float4 o;
-      if (rms) {
-        o.x = (v[it].x / m) * wv.x; o.y = (v[it].y / m) * wv.y; o.z = (v[it].z / m) * wv.z; o.w = (v[it].w / m) * wv.w;
-      } else {
-        const float4 bv = *reinterpret_cast<const float4*>(b + i);
-        o.x = ((v[it].x - mean) * inv) * wv.x + bv.x; o.y = ((v[it].y - mean) * inv) * wv.y + bv.y;
-        o.z = ((v[it].z - mean) * inv) * wv.z + bv.z; o.w = ((v[it].w - mean) * inv) * wv.w + bv.w;
-      }
-      *reinterpret_cast<float4*>(yr + i) = o;
-    }
-  }
+  block_row_sums(s, s2, red);
+  row_norm_apply(v, s, s2, d, eps, rms, w, b, y + (long)row * d);
 }
 
 // ------------------------------------------------------------------------------------------

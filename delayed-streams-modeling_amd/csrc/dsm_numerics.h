@@ -141,7 +141,9 @@ DSM_HD void dsm_sincosf(float xf, float* s_out, float* c_out) {
  * --------------------------------------------------------------------------------- */
 #define DSM_KC 256
 
-/* WAVE SUM: 64 lane partials combined by an xor butterfly, offsets 32,16,8,4,2,1
+/* ROW SUM (norms): 256 threads per row, thread t chains elements 1024*it + 4*t + j; per-wave butterfly;
+ * the 4 wave totals are added left to right.
+ * WAVE SUM: 64 lane partials combined by an xor butterfly, offsets 32,16,8,4,2,1
  * (== __shfl_xor all-reduce).  In-place; every entry ends up holding the total. */
 DSM_HD void dsm_butterfly_sum(float* p, int width /* power of two <= 64 */) {
   for (int off = width >> 1; off >= 1; off >>= 1) {

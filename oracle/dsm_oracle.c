@@ -123,21 +123,27 @@ void orc_linear(float* y, int ldy, const float* x, int ldx, const float* W, int 
 }
 
 /* ======================================================================================
- * Row reductions: one "wave" of 64 lanes per row, lane l owns elements 256*it + 4*l + j.
+ * Row reductions: one 256-thread workgroup per row; thread t owns elements 1024*it + 4*t + j and chains
+ * them (it, then j ascending); each of the 4 waves butterflies its 64 partials; the wave totals are added
+ * left to right.
  * ====================================================================================== */
 static float row_sum_canon(const float* x, int d, int squares) {
-  float part[64];
-  for (int l = 0; l < 64; ++l) {
+  float part[256];
+  for (int t = 0; t < 256; ++t) {
     float acc = 0.0f;
-    for (int it = 0; it * 256 < d; ++it)
+    for (int it = 0; it * 1024 < d; ++it)
       for (int j = 0; j < 4; ++j) {
-        int i = it * 256 + 4 * l + j;
+        int i = it * 1024 + 4 * t + j;
         if (i < d) acc = squares ? DSM_FMAF(x[i], x[i], acc) : acc + x[i];
       }
-    part[l] = acc;
+    part[t] = acc;
   }
-  dsm_butterfly_sum(part, 64);
-  return part[0];
+  float tot = 0.0f;
+  for (int w = 0; w < 4; ++w) {
+    dsm_butterfly_sum(part + 64 * w, 64);
+    tot = (w == 0) ? part[0] : tot + part[64 * w];
+  }
+  return tot;
 }
 
 /* candle_nn::ops::rms_norm — core/batched_transformer.rs:194-198 (eps 1e-8, :247) */
