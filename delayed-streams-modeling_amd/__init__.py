@@ -69,7 +69,7 @@ ABI_SYMBOLS = [
     "dsm_asr_step_pcm", "dsm_asr_poll_msgs", "dsm_asr_reset_slot", "dsm_mimi_reset_slot", "dsm_sync",
     "dsm_get_metrics", "dsm_batch_size", "dsm_n_q", "dsm_mimi_encode_step_dev", "dsm_asr_step_tokens_dev",
     "dsm_streams_join", "dsm_debug_read", "dsm_asr_step_pcm_dev", "dsm_prof_enable", "dsm_prof_read",
-    "dsm_debug_set_positions",
+    "dsm_debug_set_positions", "dsm_mimi_decode_step", "dsm_mimi_decode_step_dev",
 ]
 PROF_TAGS = ["attn_lm", "gemm_lm", "attn_mimi", "gemm_mimi", "rvq", "other"]
 
@@ -112,6 +112,10 @@ def load_library(path=None):
     lib.dsm_streams_join.argtypes = [vp]
     lib.dsm_debug_read.argtypes = [vp, C.c_char_p, fp, C.c_size_t]
     lib.dsm_asr_step_pcm_dev.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.dsm_mimi_decode_step.argtypes = [vp, u32p, u8p, fp, C.POINTER(C.c_int)]
+    lib.dsm_mimi_decode_step.restype = C.c_int
+    lib.dsm_mimi_decode_step_dev.argtypes = [vp, vp, vp, vp]
+    lib.dsm_mimi_decode_step_dev.restype = C.c_int
     lib.dsm_debug_set_positions.argtypes = [vp, C.c_uint32, C.c_uint32]
     lib.dsm_debug_set_positions.restype = C.c_int
     lib.dsm_prof_enable.argtypes = [vp, C.c_uint]
@@ -220,6 +224,17 @@ class AsrEngine:
         produced = C.c_int(0)
         self._check(self.lib.dsm_mimi_encode_step(self.h, _ptr(pcm), _ptr(mask), _ptr(codes), C.byref(produced)))
         return codes if produced.value else None
+
+    def decode_step(self, codes, mask):
+        codes = np.ascontiguousarray(codes, dtype=np.uint32).reshape(self.B, self.n_q)
+        mask = np.ascontiguousarray(mask, dtype=np.uint8).reshape(self.B)
+        pcm = np.zeros((self.B, FRAME_SIZE), dtype=np.float32)
+        produced = C.c_int(0)
+        self._check(self.lib.dsm_mimi_decode_step(self.h, _ptr(codes), _ptr(mask), _ptr(pcm), C.byref(produced)))
+        return pcm if produced.value else None
+
+    def decode_step_dev(self, d_codes, d_mask, d_pcm):
+        self._check(self.lib.dsm_mimi_decode_step_dev(self.h, d_codes, d_mask, d_pcm))
 
     def step_tokens(self, codes, mask):
         codes = np.ascontiguousarray(codes, dtype=np.uint32).reshape(self.B, self.n_q)

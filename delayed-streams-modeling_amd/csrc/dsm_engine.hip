@@ -72,7 +72,7 @@ struct TransformerState {  // per (side): ring caches + ScatteredCacheBuilder st
 };
 
 struct RvqW {
-  Linear input_proj;
+  Linear input_proj, output_proj;
   int n_q = 0;
   std::vector<Linear> codebooks;  // W = embedding [bins][dim] f32, bias = c2 [bins]
 };
@@ -86,6 +86,19 @@ struct MimiW {
   std::vector<Stage> stages;
   TransformerW tr;
   RvqW rvq_first, rvq_rest;
+  // decode side (core/mimi.rs:99-103, core/seanet.rs:305-468)
+  struct DecStage {
+    Linear up;       // convtr as a GEMM: rows kk*out_c + co, K = in_c
+    float* up_bias = nullptr;
+    int in_c = 0, out_c = 0, k = 0, stride = 0, T_in = 0;
+    ConvGeom ra, rb;
+  };
+  bool has_decoder = false;
+  ConvGeom dec_init, dec_final;
+  std::vector<DecStage> dec_stages;
+  TransformerW dec_tr;
+  float* upsample_w = nullptr;  // [k][dim]
+  const float** emb_ptrs = nullptr;  // device array of n_q codebook pointers
 };
 
 struct MimiState {  // one per side (encoder-thread clone / model side)
@@ -108,6 +121,24 @@ struct MimiState {  // one per side (encoder-thread clone / model side)
   int ds_desc = -1;  // index of the downsample conv in descs
   bool first_call = true;
   uint8_t* mask = nullptr;  // device [B]
+};
+
+struct MimiDecState {  // Mimi::decode_step state, allocated on first use
+  bool ready = false, first_call = true;
+  uint32_t* codes = nullptr;
+  uint8_t* mask = nullptr;
+  float *q_first = nullptr, *q_rest = nullptr, *emb = nullptr, *up_carry = nullptr;
+  float *x_tr = nullptr, *xn = nullptr, *q = nullptr, *att = nullptr, *ff = nullptr;
+  TransformerState tr;
+  float* cat_init = nullptr;
+  struct Stage {
+    float *x = nullptr, *z = nullptr, *carry = nullptr, *y = nullptr, *cat_ra = nullptr, *cat_rb = nullptr;
+  };
+  std::vector<Stage> stages;
+  float* cat_final = nullptr;
+  float* pcm = nullptr;
+  ConvStateDesc* descs = nullptr;
+  std::vector<ConvStateDesc> h_descs;
 };
 
 struct LmW {
@@ -144,6 +175,8 @@ struct dsm_engine {
   hipEvent_t ev_join = nullptr, ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;
   MimiW mimi_w;
   MimiState mimi[2];
+  MimiDecState dec;
+  float* h_pcm_out = nullptr;
   LmW lm_w;
   LmState lm;
   std::vector<void*> allocs;
@@ -433,6 +466,11 @@ int load_rvq(dsm_engine* e, Loader& ld, RvqW* r, const char* prefix, int n_q, co
   auto ip = ld.get((int64_t)dim * m.dimension, "%s.input_proj.weight", prefix);
   if (ld.failed) return DSM_ERR_IO;
   if (int rc = pack_linear(e, &r->input_proj, ip.data(), dim, m.dimension, false, nullptr)) return rc;
+  if (ld.has("%s.output_proj.weight", prefix)) {  // decode side; STT-only checkpoints may omit nothing, but be lenient
+    auto op = ld.get((int64_t)m.dimension * dim, "%s.output_proj.weight", prefix);
+    if (ld.failed) return DSM_ERR_IO;
+    if (int rc = pack_linear(e, &r->output_proj, op.data(), m.dimension, dim, false, nullptr)) return rc;
+  }
   r->codebooks.resize(n_q);
   for (int i = 0; i < n_q; ++i) {
     auto usage = ld.get(bins, "%s.vq.layers.%d._codebook.cluster_usage", prefix, i);
@@ -505,6 +543,81 @@ int load_mimi(dsm_engine* e, Loader& ld, MimiW* m, const dsm_mimi_config& cfg) {
   if (int rc = load_rvq(e, ld, &m->rvq_first, "quantizer.rvq_first", 1, cfg)) return rc;
   if (cfg.quantizer_n_q > 1)
     if (int rc = load_rvq(e, ld, &m->rvq_rest, "quantizer.rvq_rest", cfg.quantizer_n_q - 1, cfg)) return rc;
+  // ---- decode side: only if the checkpoint carries it (the STT worker never calls decode_step) ----
+  m->has_decoder = ld.has("decoder.model.0.conv.conv.weight") || ld.has("decoder.model.0.conv.conv.weight_v");
+  if (!m->has_decoder) return 0;
+  {
+    int mult = 1 << cfg.n_ratios, idx = 0, T = m->final_conv.T_out;  // frames per step at the encoder rate (2)
+    char p[128];
+    snprintf(p, sizeof p, "decoder.model.%d", idx);
+    if (int rc = load_conv(e, ld, &m->dec_init, p, cfg.dimension, mult * cfg.n_filters, cfg.kernel_size, 1, true, false)) return rc;
+    m->dec_init.T_in = m->dec_init.T_out = T;
+    idx += 1;
+    m->dec_stages.resize(cfg.n_ratios);
+    for (int i = 0; i < cfg.n_ratios; ++i) {
+      const int ratio = cfg.ratios[i];
+      MimiW::DecStage& st = m->dec_stages[i];
+      st.in_c = mult * cfg.n_filters;
+      st.out_c = st.in_c / 2;
+      st.k = 2 * ratio;
+      st.stride = ratio;
+      st.T_in = T;
+      snprintf(p, sizeof p, "decoder.model.%d.convtr.convtr", idx + 1);
+      std::vector<float> w;
+      if (ld.has("%s.weight", p)) {
+        w = ld.get((int64_t)st.in_c * st.out_c * st.k, "%s.weight", p);
+      } else {  // weight norm over dims (1,2) of [in_c, out_c, k] — core/conv.rs:136-139
+        auto g = ld.get(st.in_c, "%s.weight_g", p);
+        w = ld.get((int64_t)st.in_c * st.out_c * st.k, "%s.weight_v", p);
+        for (int ci = 0; ci < st.in_c && !ld.failed; ++ci) {
+          float ss = 0.0f;
+          const size_t n = (size_t)st.out_c * st.k;
+          for (size_t j = 0; j < n; ++j) ss = ss + w[ci * n + j] * w[ci * n + j];
+          float nrm = sqrtf(ss);
+          for (size_t j = 0; j < n; ++j) w[ci * n + j] = w[ci * n + j] * g[ci] / nrm;
+        }
+      }
+      auto b = ld.get(st.out_c, "%s.bias", p);
+      if (ld.failed) return DSM_ERR_IO;
+      // [in_c][out_c][k] -> rows (kk*out_c + co), K = in_c
+      std::vector<float> r((size_t)st.k * st.out_c * st.in_c);
+      for (int ci = 0; ci < st.in_c; ++ci)
+        for (int co = 0; co < st.out_c; ++co)
+          for (int kk = 0; kk < st.k; ++kk)
+            r[((size_t)kk * st.out_c + co) * st.in_c + ci] = w[((size_t)ci * st.out_c + co) * st.k + kk];
+      if (int rc = pack_linear(e, &st.up, r.data(), st.k * st.out_c, st.in_c, false, nullptr)) return rc;
+      if (int rc = e->upload(&st.up_bias, b.data(), b.size())) return rc;
+      idx += 2;
+      T *= ratio;
+      const int dim = st.out_c, hidden = dim / cfg.compress;
+      snprintf(p, sizeof p, "decoder.model.%d.block.1", idx);
+      if (int rc = load_conv(e, ld, &st.ra, p, dim, hidden, cfg.residual_kernel_size, 1, true, false)) return rc;
+      snprintf(p, sizeof p, "decoder.model.%d.block.3", idx);
+      if (int rc = load_conv(e, ld, &st.rb, p, hidden, dim, 1, 1, true, false)) return rc;
+      st.ra.T_in = st.ra.T_out = st.rb.T_in = st.rb.T_out = T;
+      idx += 1;
+      mult /= 2;
+    }
+    snprintf(p, sizeof p, "decoder.model.%d", idx + 1);
+    if (int rc = load_conv(e, ld, &m->dec_final, p, cfg.n_filters, cfg.channels, cfg.last_kernel_size, 1, true, false)) return rc;
+    m->dec_final.T_in = m->dec_final.T_out = T;
+    if (T != DSM_FRAME_SIZE) {
+      e->set_error("decoder emits %d samples per step, expected %d", T, DSM_FRAME_SIZE);
+      return DSM_ERR_INVALID;
+    }
+    if (int rc = load_transformer(e, ld, &m->dec_tr, cfg.transformer, "decoder_transformer.transformer", false)) return rc;
+    const int st_ = cfg.downsample_stride, dim = cfg.dimension;
+    auto uw = ld.get((int64_t)dim * 2 * st_, "upsample.convtr.convtr.convtr.weight");  // [dim][1][k]
+    if (ld.failed) return DSM_ERR_IO;
+    std::vector<float> ur((size_t)2 * st_ * dim);
+    for (int c = 0; c < dim; ++c)
+      for (int kk = 0; kk < 2 * st_; ++kk) ur[(size_t)kk * dim + c] = uw[(size_t)c * 2 * st_ + kk];
+    if (int rc = e->upload(&m->upsample_w, ur.data(), ur.size())) return rc;
+    std::vector<const float*> ptrs;
+    ptrs.push_back(reinterpret_cast<const float*>(m->rvq_first.codebooks[0].w));
+    for (auto& cb : m->rvq_rest.codebooks) ptrs.push_back(reinterpret_cast<const float*>(cb.w));
+    if (int rc = e->upload(&m->emb_ptrs, ptrs.data(), ptrs.size())) return rc;
+  }
   return 0;
 }
 

@@ -920,6 +920,102 @@ __global__ void rvq_select_kernel(const float* __restrict__ pval, const uint32_t
     residual[(long)m * dim + i] = residual[(long)m * dim + i] - E[(long)c * ldE + i];
 }
 
+// ------------------------------------------------------------------------------------------
+// Decode side (Mimi::decode_step, core/mimi.rs:217-225)
+// ------------------------------------------------------------------------------------------
+// ResidualVectorQuantization::decode — core/quantization.rs:231-248: gather E_i[code_i] and sum the layers in order.
+// One workgroup per slot; q_first = layer 0 of rvq_first, q_rest = sum over rvq_rest layers.
+struct RvqGatherArgs {
+  const float* const* emb;  // n_q device pointers: [bins][ldE] f32 (index 0 = rvq_first, 1.. = rvq_rest)
+  int n_q, bins, dim, ldE;
+};
+__global__ void rvq_gather_sum_kernel(RvqGatherArgs a, const uint32_t* __restrict__ codes, float* __restrict__ q_first,
+                                      float* __restrict__ q_rest) {
+  const int b = blockIdx.x;
+  for (int dd = threadIdx.x; dd < a.dim; dd += blockDim.x) {
+    uint32_t c0 = codes[b * a.n_q];
+    c0 = c0 < (uint32_t)a.bins ? c0 : 0u;
+    q_first[(long)b * a.dim + dd] = a.emb[0][(long)c0 * a.ldE + dd];
+    float acc = 0.0f;
+    for (int i = 1; i < a.n_q; ++i) {
+      uint32_t c = codes[b * a.n_q + i];
+      c = c < (uint32_t)a.bins ? c : 0u;
+      float ev = a.emb[i][(long)c * a.ldE + dd];
+      acc = (i == 1) ? ev : acc + ev;
+    }
+    if (a.n_q > 1) q_rest[(long)b * a.dim + dd] = acc;
+  }
+}
+
+// ConvTrUpsample1d::step — depthwise ConvTranspose1d k = 2*stride, one input frame per step, no bias
+// (core/conv.rs:558-606, :448-501).  x [B][C]; w [k][C]; carry [B][k - s][C]; y [B][s][C].
+__global__ void upsample_dw_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ carry,
+                                   float* __restrict__ y, const uint8_t* __restrict__ active, int C, int s, int k,
+                                   int has_state) {
+  const int b = blockIdx.x;
+  for (int i = threadIdx.x; i < s * C; i += blockDim.x) {
+    const int o = i / C, c = i % C;
+    const float xv = x[(long)b * C + c];
+    float v = xv * w[(long)o * C + c];
+    if (has_state) v = v + carry[((long)b * (k - s) + o) * C + c];
+    y[((long)b * s + o) * C + c] = v;
+    if (o < k - s) {  // k - s == s: the thread that consumed carry[o] also refreshes it (no cross-thread hazard)
+      const float nv = xv * w[(long)(s + o) * C + c];
+      float* cp = &carry[((long)b * (k - s) + o) * C + c];
+      if (active[b]) *cp = nv;
+      else if (!has_state) *cp = 0.0f;
+    }
+  }
+}
+
+// StreamableConvTranspose1d::step epilogue — core/conv.rs:448-501 with k == 2*stride.  The GEMM produced
+// z[(b,t)][kk*OC + co] = sum_ci x[b][t][ci] * w[ci][co][kk]; output frame o = t*s + kk (kk < s) is
+//   t == 0 : (z[t][kk] + bias) + (carry[kk] - bias)          (first call of the module: no carry term)
+//   t  > 0 : (z[t-1][kk+s] + z[t][kk]) + bias
+// new carry[j] = z[T-1][j+s] + bias (kept for inactive slots).  Writes y (raw) and/or y2 (ELU copy).
+struct OverlapAddArgs {
+  const float* z;
+  const float* bias;
+  float* carry;  // [B][s][OC]
+  const uint8_t* active;
+  int T, s, OC, has_state;
+  float* Y;
+  RowMap ymap;  // rows are (b, o), rpb = T*s
+  float* Y2;
+  RowMap y2map;
+};
+__global__ void convtr_overlap_add_kernel(OverlapAddArgs a) {
+  const int b = blockIdx.y;
+  const int per_b = a.T * a.s * (a.OC >> 2);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < per_b; i += gridDim.x * blockDim.x) {
+    const int c4 = i % (a.OC >> 2), o = i / (a.OC >> 2);
+    const int co = c4 * 4, t = o / a.s, kk = o % a.s;
+    const long ldz = (long)2 * a.s * a.OC;
+    const float4 zb = *reinterpret_cast<const float4*>(a.z + ((long)b * a.T + t) * ldz + (long)kk * a.OC + co);
+    const float4 bs = *reinterpret_cast<const float4*>(a.bias + co);
+    float4 v;
+    if (t > 0) {
+      const float4 za = *reinterpret_cast<const float4*>(a.z + ((long)b * a.T + t - 1) * ldz + (long)(kk + a.s) * a.OC + co);
+      v.x = (za.x + zb.x) + bs.x; v.y = (za.y + zb.y) + bs.y; v.z = (za.z + zb.z) + bs.z; v.w = (za.w + zb.w) + bs.w;
+    } else {
+      v.x = zb.x + bs.x; v.y = zb.y + bs.y; v.z = zb.z + bs.z; v.w = zb.w + bs.w;
+      float* cp = a.carry + ((long)b * a.s + kk) * a.OC + co;
+      if (a.has_state) {
+        const float4 cv = *reinterpret_cast<const float4*>(cp);
+        v.x = v.x + (cv.x - bs.x); v.y = v.y + (cv.y - bs.y); v.z = v.z + (cv.z - bs.z); v.w = v.w + (cv.w - bs.w);
+      }
+      const float4 zl = *reinterpret_cast<const float4*>(a.z + ((long)b * a.T + a.T - 1) * ldz + (long)(kk + a.s) * a.OC + co);
+      if (a.active[b])
+        *reinterpret_cast<float4*>(cp) = make_float4(zl.x + bs.x, zl.y + bs.y, zl.z + bs.z, zl.w + bs.w);
+      else if (!a.has_state)
+        *reinterpret_cast<float4*>(cp) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int m = b * a.T * a.s + o;
+    if (a.Y) *reinterpret_cast<float4*>(a.Y + a.ymap.off(m) + co) = v;
+    if (a.Y2) *reinterpret_cast<float4*>(a.Y2 + a.y2map.off(m) + co) = make_float4(dsm_elu(v.x), dsm_elu(v.y), dsm_elu(v.z), dsm_elu(v.w));
+  }
+}
+
 __global__ void fill_u32_kernel(uint32_t* p, uint32_t v, long n) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;

@@ -147,6 +147,16 @@ int dsm_mimi_encode_step(dsm_engine*, const float* pcm, const uint8_t* mask, uin
                          int* produced);
 
 /*
+ * Mimi::decode_step(&StreamTensor codes [B,n_q,1], &StreamMask) — core/mimi.rs:217-225 (called by the TTS worker at
+ * srv/tts.rs:538): quantizer decode -> ConvTr upsample -> decoder transformer -> SEANet decoder.
+ * codes: host [B*n_q] u32 (values < quantizer_bins); pcm_out: host [B*1920] f32.  *produced = samples per slot.
+ * The decode state is allocated on first use and belongs to the encoder-side Mimi (dsm_mimi_reset_slot resets its conv
+ * carries; like the reference it does NOT reset the decoder transformer: core/mimi.rs:237-238).
+ */
+int dsm_mimi_decode_step(dsm_engine*, const uint32_t* codes, const uint8_t* mask, float* pcm_out, int* produced);
+int dsm_mimi_decode_step_dev(dsm_engine*, const uint32_t* d_codes, const uint8_t* d_mask, float* d_pcm_out);
+
+/*
  * asr::State::step_tokens(&Tensor[B,n_q,1], None, &StreamMask, f) — core/asr.rs:147-255,
  * called at srv/batched_asr.rs:476 (model thread).  codes: host [B*n_q] u32 or NULL (use the
  * device-resident output of the last encode step).  text_tokens_out: host [B] u32 (argmax

@@ -876,6 +876,147 @@ static void seanet_enc_reset_batch_idx(orc_seanet_enc* e, int b) { /* core/seane
 }
 
 /* ======================================================================================
+ * SeaNetDecoder — core/seanet.rs:305-468
+ * ====================================================================================== */
+typedef struct {
+  orc_convtr1d* up; /* StreamableConvTranspose1d k = 2*ratio, stride = ratio — core/seanet.rs:353-363 */
+  int n_res;
+  orc_resblock* res;
+} orc_dec_layer;
+
+typedef struct {
+  int B;
+  orc_conv1d* init_conv;
+  int n_layers;
+  orc_dec_layer* layers;
+  orc_conv1d* final_conv;
+} orc_seanet_dec;
+
+static orc_convtr1d* load_convtr1d(wsrc* s, int B, const char* prefix, int in_c, int out_c, int k, int stride) {
+  char p[256];
+  snprintf(p, sizeof p, "%s.convtr.convtr", prefix); /* StreamableConvTranspose1d -> NormConvTranspose1d: pp("convtr").pp("convtr") */
+  float* w;
+  if (w_has(s, "%s.weight", p)) {
+    w = w_get(s, (int64_t)in_c * out_c * k, "%s.weight", p);
+  } else { /* weight norm over dims (1,2) of [in_c, out_c, k] — core/conv.rs:136-139 */
+    float* g = w_get(s, in_c, "%s.weight_g", p);
+    w = w_get(s, (int64_t)in_c * out_c * k, "%s.weight_v", p);
+    for (int ci = 0; ci < in_c; ++ci) {
+      float ss = 0.0f;
+      for (int i = 0; i < out_c * k; ++i) ss = ss + w[(size_t)ci * out_c * k + i] * w[(size_t)ci * out_c * k + i];
+      float nrm = sqrtf(ss);
+      for (int i = 0; i < out_c * k; ++i) w[(size_t)ci * out_c * k + i] = w[(size_t)ci * out_c * k + i] * g[ci] / nrm;
+    }
+    free(g);
+  }
+  float* b = w_get(s, out_c, "%s.bias", p);
+  orc_convtr1d* c = orc_convtr1d_new(B, in_c, out_c, k, stride, 0, w, b);
+  free(w);
+  free(b);
+  return c;
+}
+
+static orc_seanet_dec* seanet_dec_load(wsrc* s, int B, const dsm_mimi_config* cfg) {
+  orc_seanet_dec* d = (orc_seanet_dec*)xcalloc(1, sizeof *d);
+  d->B = B;
+  int mult = 1 << cfg->n_ratios, layer_idx = 0;
+  char p[128];
+  snprintf(p, sizeof p, "decoder.model.%d", layer_idx);
+  d->init_conv = load_conv1d(s, B, p, cfg->dimension, mult * cfg->n_filters, cfg->kernel_size, 1, 1, 0, 1);
+  layer_idx += 1;
+  d->n_layers = cfg->n_ratios;
+  d->layers = (orc_dec_layer*)xcalloc(cfg->n_ratios, sizeof(orc_dec_layer));
+  for (int i = 0; i < cfg->n_ratios; ++i) {
+    int ratio = cfg->ratios[i];
+    orc_dec_layer* L = &d->layers[i];
+    snprintf(p, sizeof p, "decoder.model.%d", layer_idx + 1);
+    L->up = load_convtr1d(s, B, p, mult * cfg->n_filters, mult * cfg->n_filters / 2, ratio * 2, ratio);
+    layer_idx += 2;
+    L->n_res = cfg->n_residual_layers;
+    L->res = (orc_resblock*)xcalloc(L->n_res, sizeof(orc_resblock));
+    int dim = mult * cfg->n_filters / 2, hidden = dim / cfg->compress;
+    for (int j = 0; j < L->n_res; ++j) {
+      int dil = 1;
+      for (int q = 0; q < j; ++q) dil *= cfg->dilation_base;
+      snprintf(p, sizeof p, "decoder.model.%d.block.1", layer_idx);
+      L->res[j].block[0] = load_conv1d(s, B, p, dim, hidden, cfg->residual_kernel_size, 1, dil, 0, 1);
+      snprintf(p, sizeof p, "decoder.model.%d.block.3", layer_idx);
+      L->res[j].block[1] = load_conv1d(s, B, p, hidden, dim, 1, 1, 1, 0, 1);
+      layer_idx += 1;
+    }
+    mult /= 2;
+  }
+  snprintf(p, sizeof p, "decoder.model.%d", layer_idx + 1);
+  d->final_conv = load_conv1d(s, B, p, cfg->n_filters, cfg->channels, cfg->last_kernel_size, 1, 1, 0, 1);
+  return d;
+}
+
+static void seanet_dec_free(orc_seanet_dec* d) {
+  if (!d) return;
+  orc_conv1d_free(d->init_conv);
+  for (int i = 0; i < d->n_layers; ++i) {
+    orc_convtr1d_free(d->layers[i].up);
+    for (int j = 0; j < d->layers[i].n_res; ++j) {
+      orc_conv1d_free(d->layers[i].res[j].block[0]);
+      orc_conv1d_free(d->layers[i].res[j].block[1]);
+    }
+    free(d->layers[i].res);
+  }
+  free(d->layers);
+  orc_conv1d_free(d->final_conv);
+  free(d);
+}
+
+/* SeaNetDecoder::step — core/seanet.rs:452-467.  x [B][T][dimension] -> pcm [B][T'][channels] */
+static int seanet_dec_step(orc_seanet_dec* d, const float* x, int T, const uint8_t* mask, float** out) {
+  const int B = d->B;
+  int C = d->init_conv->out_c;
+  float* cur = (float*)xmalloc(sizeof(float) * (size_t)B * T * C);
+  int Tc = orc_conv1d_step(d->init_conv, x, T, mask, cur, T);
+  for (int i = 0; i < d->n_layers && Tc > 0; ++i) {
+    orc_dec_layer* L = &d->layers[i];
+    elu_inplace(cur, (size_t)B * Tc * C);
+    int C2 = L->up->out_c;
+    int cap = Tc * L->up->stride + L->up->k;
+    float* nx = (float*)xmalloc(sizeof(float) * (size_t)B * cap * C2);
+    int Tn = orc_convtr1d_step(L->up, cur, Tc, mask, nx, cap);
+    free(cur);
+    cur = nx;
+    Tc = Tn;
+    C = C2;
+    for (int j = 0; j < L->n_res && Tc > 0; ++j) {
+      float* r = (float*)xmalloc(sizeof(float) * (size_t)B * Tc * C);
+      resblock_step(&L->res[j], B, cur, Tc, C, mask, r);
+      free(cur);
+      cur = r;
+    }
+  }
+  if (Tc > 0) {
+    elu_inplace(cur, (size_t)B * Tc * C);
+    int C2 = d->final_conv->out_c;
+    float* nx = (float*)xmalloc(sizeof(float) * (size_t)B * Tc * C2);
+    int Tn = orc_conv1d_step(d->final_conv, cur, Tc, mask, nx, Tc);
+    free(cur);
+    cur = nx;
+    Tc = Tn;
+  }
+  *out = cur; /* final_activation = None (core/mimi.rs:43) */
+  return Tc;
+}
+
+static void seanet_dec_reset_batch_idx(orc_seanet_dec* d, int b) { /* core/seanet.rs:410-420 */
+  orc_conv1d_reset_batch_idx(d->init_conv, b);
+  orc_conv1d_reset_batch_idx(d->final_conv, b);
+  for (int i = 0; i < d->n_layers; ++i) {
+    orc_convtr1d_reset_batch_idx(d->layers[i].up, b);
+    for (int j = 0; j < d->layers[i].n_res; ++j) {
+      orc_conv1d_reset_batch_idx(d->layers[i].res[j].block[0], b);
+      orc_conv1d_reset_batch_idx(d->layers[i].res[j].block[1], b);
+    }
+  }
+}
+
+/* ======================================================================================
  * batched_transformer::StreamingTransformer — core/batched_transformer.rs:19-513
  * ====================================================================================== */
 typedef struct {
@@ -1122,6 +1263,23 @@ static void rvq_encode(const orc_rvq* r, const float* xs, int rows, uint32_t* co
   free(dots);
 }
 
+/* ResidualVectorQuantizer::decode — core/quantization.rs:312-320 + ResidualVectorQuantization::decode :231-248 +
+ * EuclideanCodebook::decode :143-152: gather + sequential sum over the layers, then the 1x1 output_proj.
+ * codes[row*stride + off + i]; out [rows][in_dim] */
+static void rvq_decode(const orc_rvq* r, const uint32_t* codes, int rows, int stride_codes, int code_off, float* out) {
+  const int dim = r->dim, bins = r->bins;
+  float* q = (float*)xmalloc(sizeof(float) * (size_t)rows * dim);
+  for (int m = 0; m < rows; ++m)
+    for (int i = 0; i < r->n_q; ++i) {
+      uint32_t c = codes[(size_t)m * stride_codes + code_off + i];
+      if (c >= (uint32_t)bins) c = 0; /* index_select would bail; callers pass valid codes */
+      const float* e = r->embedding + ((size_t)i * bins + c) * dim;
+      for (int dd = 0; dd < dim; ++dd) q[(size_t)m * dim + dd] = (i == 0) ? e[dd] : q[(size_t)m * dim + dd] + e[dd];
+    }
+  orc_linear(out, r->in_dim, q, dim, r->output_proj, dim, NULL, rows, r->in_dim, dim);
+  free(q);
+}
+
 /* ======================================================================================
  * Mimi (encode side) — core/mimi.rs:96-206
  * ====================================================================================== */
@@ -1132,6 +1290,10 @@ typedef struct {
   orc_transformer* enc_tr;
   orc_conv1d* downsample; /* ConvDownsample1d: k = 2*stride, replicate pad, no bias — core/conv.rs:520-533 */
   orc_rvq *rvq_first, *rvq_rest;
+  /* decode side — core/mimi.rs:99-103 */
+  orc_seanet_dec* decoder;
+  orc_transformer* dec_tr;
+  orc_convtr1d* upsample; /* ConvTrUpsample1d: depthwise k = 2*stride, no bias — core/conv.rs:573-584 */
   /* debug taps of the last step */
   float *dbg_seanet, *dbg_tr, *dbg_latent;
   int dbg_T, dbg_Tl;
@@ -1149,6 +1311,14 @@ static orc_mimi* mimi_load(wsrc* s, int B, const dsm_mimi_config* cfg) {
     m->downsample = orc_conv1d_new(B, dim, dim, 2 * st, st, 1, 1, w, NULL);
     free(w);
   }
+  m->decoder = seanet_dec_load(s, B, cfg);
+  m->dec_tr = transformer_load(s, B, &cfg->transformer, "decoder_transformer.transformer", 0);
+  {
+    int dim = cfg->dimension, st = cfg->downsample_stride;
+    float* w = w_get(s, (int64_t)dim * 2 * st, "upsample.convtr.convtr.convtr.weight");
+    m->upsample = orc_convtr1d_new(B, dim, dim, 2 * st, st, 1, w, NULL);
+    free(w);
+  }
   m->rvq_first = rvq_load(s, "quantizer.rvq_first", 1, cfg->quantizer_bins, cfg->quantizer_dim, cfg->dimension);
   m->rvq_rest = cfg->quantizer_n_q > 1
                     ? rvq_load(s, "quantizer.rvq_rest", cfg->quantizer_n_q - 1, cfg->quantizer_bins, cfg->quantizer_dim, cfg->dimension)
@@ -1162,6 +1332,9 @@ static void mimi_free(orc_mimi* m) {
   orc_conv1d_free(m->downsample);
   rvq_free(m->rvq_first);
   rvq_free(m->rvq_rest);
+  seanet_dec_free(m->decoder);
+  transformer_free(m->dec_tr);
+  orc_convtr1d_free(m->upsample);
   free(m->dbg_seanet); free(m->dbg_tr); free(m->dbg_latent);
   free(m);
 }
@@ -1203,10 +1376,41 @@ static int mimi_encode_step(orc_mimi* m, const float* pcm, int T, const uint8_t*
   return Tl;
 }
 
-/* Mimi::reset_batch_idx — core/mimi.rs:236-244 (encode-side members) */
+/* Mimi::decode_step — core/mimi.rs:217-225.  codes [B][n_q][1] -> pcm [B][T'][channels]; returns T' */
+static int mimi_decode_step(orc_mimi* m, const uint32_t* codes, const uint8_t* mask, float* pcm_out, int cap) {
+  const int B = m->B, dim = m->cfg.dimension, n_q = m->cfg.quantizer_n_q;
+  /* SplitResidualVectorQuantizer::decode — core/quantization.rs:380-390: first + rest */
+  float* emb = (float*)xmalloc(sizeof(float) * (size_t)B * dim);
+  rvq_decode(m->rvq_first, codes, B, n_q, 0, emb);
+  if (m->rvq_rest) {
+    float* rest = (float*)xmalloc(sizeof(float) * (size_t)B * dim);
+    rvq_decode(m->rvq_rest, codes, B, n_q, 1, rest);
+    for (size_t i = 0; i < (size_t)B * dim; ++i) emb[i] = emb[i] + rest[i];
+    free(rest);
+  }
+  int up_cap = m->upsample->stride + m->upsample->k;
+  float* up = (float*)xmalloc(sizeof(float) * (size_t)B * up_cap * dim);
+  int Tu = orc_convtr1d_step(m->upsample, emb, 1, mask, up, up_cap);
+  free(emb);
+  if (Tu == 0) { free(up); return 0; }
+  transformer_forward(m->dec_tr, up, Tu, mask); /* decoder_transformer.step */
+  float* pcm = NULL;
+  int Tp = seanet_dec_step(m->decoder, up, Tu, mask, &pcm);
+  free(up);
+  if (Tp > cap) { free(pcm); return -1; }
+  memcpy(pcm_out, pcm, sizeof(float) * (size_t)B * Tp * m->cfg.channels);
+  free(pcm);
+  return Tp;
+}
+
+/* Mimi::reset_batch_idx — core/mimi.rs:236-244.  NB the reference resets encoder_transformer twice and never
+ * decoder_transformer (:237-238); restated as written. */
 static void mimi_reset_batch_idx(orc_mimi* m, int b) {
   orc_kvb_reset_batch_index(m->enc_tr->builder, b);
+  orc_kvb_reset_batch_index(m->enc_tr->builder, b);
   seanet_enc_reset_batch_idx(m->encoder, b);
+  seanet_dec_reset_batch_idx(m->decoder, b);
+  orc_convtr1d_reset_batch_idx(m->upsample, b);
   orc_conv1d_reset_batch_idx(m->downsample, b);
 }
 
@@ -1369,6 +1573,10 @@ void orc_asr_destroy(orc_asr* a) {
 
 int orc_mimi_encode_step(orc_asr* a, int side, const float* pcm, const uint8_t* mask, uint32_t* codes_out) {
   return mimi_encode_step(a->mimi[side ? 1 : 0], pcm, DSM_FRAME_SIZE, mask, codes_out);
+}
+
+int orc_mimi_decode_step(orc_asr* a, int side, const uint32_t* codes, const uint8_t* mask, float* pcm_out) {
+  return mimi_decode_step(a->mimi[side ? 1 : 0], codes, mask, pcm_out, DSM_FRAME_SIZE);
 }
 
 /* State::step_tokens — core/asr.rs:147-255 (steps == 1: codes [B][codebooks][1]) */

@@ -29,6 +29,8 @@ orc_asr* orc_asr_create(const dsm_asr_config* cfg, int batch_size, const char* l
 void orc_asr_destroy(orc_asr*);
 /* side: 0 = encoder-thread Mimi clone, 1 = model-side Mimi (asr::State::audio_tokenizer). */
 int orc_mimi_encode_step(orc_asr*, int side, const float* pcm, const uint8_t* mask, uint32_t* codes_out);
+/* Mimi::decode_step: codes [B*n_q] -> pcm_out [B*1920]; returns samples per slot */
+int orc_mimi_decode_step(orc_asr*, int side, const uint32_t* codes, const uint8_t* mask, float* pcm_out);
 int orc_asr_step_tokens(orc_asr*, const uint32_t* codes, const uint8_t* mask, uint32_t* text_tokens_out,
                         float* vad_prs_out);
 int orc_asr_reset_slot(orc_asr*, int slot);

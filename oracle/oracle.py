@@ -33,6 +33,7 @@ def lib():
         L.orc_asr_destroy.restype = None
         L.orc_mimi_encode_step.argtypes = [vp, C.c_int, vp, vp, vp]
         L.orc_asr_step_tokens.argtypes = [vp, vp, vp, vp, vp]
+        L.orc_mimi_decode_step.argtypes = [vp, C.c_int, vp, vp, vp]
         L.orc_asr_reset_slot.argtypes = [vp, C.c_int]
         L.orc_mimi_reset_slot.argtypes = [vp, C.c_int, C.c_int]
         L.orc_asr_poll_msgs.argtypes = [vp, C.POINTER(AsrMsg), C.c_int, vp, C.c_int]
@@ -119,6 +120,13 @@ class OracleAsr:
         codes = np.zeros((self.B, self.n_q), dtype=np.uint32)
         n = self.L.orc_mimi_encode_step(self.h, side, p(pcm), p(mask), p(codes))
         return codes if n else None
+
+    def decode_step(self, codes, mask, side=0):
+        codes = np.ascontiguousarray(codes, dtype=np.uint32).reshape(self.B, self.n_q)
+        mask = np.ascontiguousarray(mask, dtype=np.uint8).reshape(self.B)
+        pcm = np.zeros((self.B, FRAME_SIZE), dtype=np.float32)
+        n = self.L.orc_mimi_decode_step(self.h, side, p(codes), p(mask), p(pcm))
+        return pcm if n > 0 else None
 
     def step_tokens(self, codes, mask):
         codes = np.ascontiguousarray(codes, dtype=np.uint32).reshape(self.B, self.n_q)
