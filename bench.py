@@ -33,6 +33,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64, help="stream slots per GPU")
     ap.add_argument("--config", default="stt-1b-en_fr", choices=["stt-1b-en_fr", "stt-2.6b-en", "tiny"])
+    ap.add_argument("--workload", default="stt", choices=["stt", "mimi-decode"],
+                    help="stt = Mimi encode + LM decode (the headline metric); mimi-decode = Mimi::decode_step only (config 5)")
     ap.add_argument("--no-fill", action="store_true", help="skip the untimed ring-cache fill (debug only)")
     ap.add_argument("--fast-fill", action="store_true",
                     help="profiling aid: jump the ring positions to steady state instead of running `context` fill steps")
@@ -67,6 +69,37 @@ def cpu_baseline(cfg, B, lm_path, mimi_path, n_steps):
             "cores": cores, "kind": "port",
             "sample": f"{n_steps} frames x {B} streams right after reset (KV fill <= {n_steps + 1}), "
                       f"{dt * 1000:.0f} ms/step, oracle load {load_s:.0f} s; Candle itself cannot be built offline"}
+
+
+def bench_decode(args, eng, cfg, B, dev, world, rank, dist, torch):
+    """BASELINE.json configs[4] (TTS path, Mimi decode side only): codes -> PCM for B slots per 80 ms frame."""
+    rng = np.random.default_rng(1 + rank)
+    n_q = cfg.mimi.quantizer_n_q
+    codes = torch.from_numpy(rng.integers(0, cfg.mimi.quantizer_bins, (16, B, n_q)).astype(np.int32)).to(dev)
+    mask = torch.ones(B, dtype=torch.uint8, device=dev)
+    pcm = torch.zeros(B * 1920, dtype=torch.float32, device=dev)
+    it = 0
+    if args.fast_fill or not args.no_fill:
+        for _ in range(cfg.mimi.transformer.context // 2 + 4):  # decoder transformer ring (250 @ 25 Hz) full
+            eng.decode_step_dev(codes[it % 16].data_ptr(), mask.data_ptr(), pcm.data_ptr())
+            it += 1
+    for _ in range(args.warmup):
+        eng.decode_step_dev(codes[it % 16].data_ptr(), mask.data_ptr(), pcm.data_ptr())
+        it += 1
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.decode_step_dev(codes[it % 16].data_ptr(), mask.data_ptr(), pcm.data_ptr())
+        it += 1
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / args.steps * 1000
+    if rank == 0:
+        print(json.dumps({"metric": "Mimi decode_step real-time stream throughput @ bs=%d" % B, "value": world * B * 0.08 / (ms / 1000),
+                          "unit": "x realtime (stream-seconds of audio per wall second)", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "f32", "data": "synthetic", "rtf": 80.0 / ms,
+                          "config": {"workload": "Mimi v0_1 decode_step (32 codebooks -> 1920 samples), batch=%d" % B}}))
+    eng.close()
 
 
 def main():
@@ -117,6 +150,8 @@ def main():
         for p in (lm_path, mimi_path):
             os.remove(p)
 
+    if args.workload == "mimi-decode":
+        return bench_decode(args, eng, cfg, B, dev, world, rank, dist, torch)
     ctx = cfg.lm.context
     n_pcm = 16
     pcm = torch.from_numpy(synth.synth_pcm(B, n_pcm, seed=1000 + 7919 * rank)).to(dev)  # [n_pcm, B, 1920]

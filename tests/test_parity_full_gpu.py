@@ -1,0 +1,72 @@
+"""Parity at BASELINE.json's real shapes (stt-1b-en_fr: d 2048, 16 heads x 128, 16 layers, ctx 750, hidden 5632,
+32 codebooks x 2048 x 256, real Mimi v0_1) on a small batch so that the CPU oracle finishes in seconds per step.
+Exercises the code paths the tiny model cannot: 22-chunk split-K (K = 5632), hd = 128 attention, K = 8192 convs,
+the 1-channel K = 7 input conv, 32-stage RVQ."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def full_weights(dsm):
+    from dsm_amd import synth
+    import os
+    cfg = dsm.config_stt_1b_en_fr()
+    return cfg, synth.make_synth_weights(cfg, os.environ.get("DSM_WEIGHTS_DIR", "/tmp/dsm_weights"), tag="stt-1b-en_fr")
+
+
+def test_full_size_encode_lm_and_decode(gpu, dsm, lib, orc, full_weights):
+    from dsm_amd import synth
+    cfg, (lm, mimi) = full_weights
+    B, steps = 3, 4
+    eng = dsm.AsrEngine(cfg, B, lm, mimi)
+    ora = orc.OracleAsr(cfg, B, lm, mimi)
+    pcm = synth.synth_pcm(B, steps)
+    masks = [[1, 1, 1], [1, 0, 1], [1, 1, 1], [0, 1, 1]]
+    for s in range(steps):
+        if s == 2:
+            eng.reset_batch_idx(1); ora.reset_batch_idx(1)
+            eng.mimi_reset_batch_idx(1); ora.mimi_reset_batch_idx(1, side=0)
+        mask = np.array(masks[s], dtype=np.uint8)
+        act = mask.astype(bool)
+        ec = eng.encode_step(pcm[s], mask)
+        oc = ora.encode_step(pcm[s], mask)
+        assert np.array_equal(ec[act], oc[act]), f"codes differ at step {s}"
+        et, ep = eng.step_tokens(oc, mask)
+        ot, op = ora.step_tokens(oc, mask)
+        lg_e = eng.debug_read("lm.logits", B * cfg.text_out_vocab_size).reshape(B, -1)
+        lg_o = ora.debug_read("lm.logits", B * cfg.text_out_vocab_size).reshape(B, -1)
+        assert np.array_equal(lg_e[act].view(np.uint32), lg_o[act].view(np.uint32)), f"logits differ at step {s}"
+        assert np.array_equal(et[act], ot[act]) and np.array_equal(ep[:, act].view(np.uint32), op[:, act].view(np.uint32))
+        # decode the oracle's codes back to PCM on both sides (inactive slots: valid but unused codes)
+        dc = np.where(act[:, None], oc, 0).astype(np.uint32)
+        pe = eng.decode_step(dc, mask)
+        po = ora.decode_step(dc, mask, side=0)
+        assert np.array_equal(pe[act].view(np.uint32), po[act].view(np.uint32)), f"decoded PCM differs at step {s}"
+    eng.close()
+    ora.close()
+
+
+def test_stt_2_6b_en_shapes(gpu, dsm, lib, orc):
+    """BASELINE.json configs[2]: stt-2.6b-en (48 layers, 32 heads x 64, ctx 375, vocab 4000, no extra heads)."""
+    import os
+    from dsm_amd import synth
+    cfg = dsm.config_stt_2_6b_en()
+    lm, mimi = synth.make_synth_weights(cfg, os.environ.get("DSM_WEIGHTS_DIR", "/tmp/dsm_weights"), tag="stt-2.6b-en")
+    B = 2
+    eng = dsm.AsrEngine(cfg, B, lm, mimi)
+    ora = orc.OracleAsr(cfg, B, lm, mimi)
+    pcm = synth.synth_pcm(B, 2)
+    mask = np.ones(B, dtype=np.uint8)
+    for s in range(2):
+        ec, et, _ = eng.step_pcm(pcm[s], mask)
+        oc, ot, _ = ora.step_pcm(pcm[s], mask)
+        assert np.array_equal(ec, oc) and np.array_equal(et, ot)
+        hid_e = eng.debug_read("lm.hidden", B * cfg.lm.d_model)
+        hid_o = ora.debug_read("lm.hidden", B * cfg.lm.d_model)
+        assert np.array_equal(hid_e.view(np.uint32), hid_o.view(np.uint32))
+    eng.close()
+    ora.close()
+    for p in (lm,):  # 5 GB: do not leave it in /tmp for the next test session
+        os.remove(p)
