@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -183,6 +184,7 @@ struct dsm_engine {
   std::string err;
   // host staging (pinned)
   float* h_pcm = nullptr;
+  float* h_pcm1 = nullptr;
   uint8_t* h_mask = nullptr;
   uint32_t *h_codes = nullptr, *h_text = nullptr;
   float* h_prs = nullptr;
@@ -197,7 +199,10 @@ struct dsm_engine {
   size_t gemm_ws_cap[2] = {0, 0};
   // per-kernel-class event timing (dsm_prof_*)
   unsigned prof_mask = 0;
-  int tag_gemm = DSM_PROF_OTHER, tag_attn = DSM_PROF_OTHER;
+  // one slot per stream (0 = encoder, 1 = model): the two host threads of the worker never share a slot
+  int tag_gemm[2] = {DSM_PROF_OTHER, DSM_PROF_OTHER}, tag_attn[2] = {DSM_PROF_OTHER, DSM_PROF_OTHER};
+  std::mutex prof_mu, err_mu;
+  int sid(hipStream_t st) const { return st == s_enc ? 0 : 1; }
   struct ProfRec {
     int tag;
     hipEvent_t a, b;
@@ -220,13 +225,16 @@ struct dsm_engine {
   // bracket one launch: returns an index to close with prof_end, or -1 when the class is not selected
   int prof_begin(int tag, hipStream_t st) {
     if (!(prof_mask & (1u << tag))) return -1;
+    std::lock_guard<std::mutex> lk(prof_mu);
     ProfRec r{tag, prof_event(), prof_event()};
     (void)hipEventRecord(r.a, st);
     prof_recs.push_back(r);
     return (int)prof_recs.size() - 1;
   }
   void prof_end(int h, hipStream_t st) {
-    if (h >= 0) (void)hipEventRecord(prof_recs[h].b, st);
+    if (h < 0) return;
+    std::lock_guard<std::mutex> lk(prof_mu);
+    (void)hipEventRecord(prof_recs[h].b, st);
   }
 
   void set_error(const char* fmt, ...) {
@@ -235,6 +243,7 @@ struct dsm_engine {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
+    std::lock_guard<std::mutex> lk(err_mu);
     err = buf;
   }
 
@@ -706,7 +715,7 @@ int launch_gemm_tiled(dsm_engine* e, hipStream_t st, GemmArgs& a) {
     a.ws = e->gemm_ws[wsid];
   }
   dim3 grid(gx, chunks, (a.M + 16 * MT - 1) / (16 * MT));
-  const int ph = e->prof_begin(e->tag_gemm, st);
+  const int ph = e->prof_begin(e->tag_gemm[e->sid(st)], st);
   if (MT == 4)
     hipLaunchKernelGGL((gemm_tile_kernel<WT, KVT, 4, NT, EPI>), grid, dim3(256), 0, st, a);
   else if (MT == 2)
@@ -759,7 +768,7 @@ int launch_gemm_t(dsm_engine* e, hipStream_t st, GemmArgs& a, bool aligned) {
   size_t lds = chunks > 1 ? (size_t)chunks * NT * MT * 1024 : 0;
 #define DSM_LAUNCH(MTv, AL) \
   hipLaunchKernelGGL((gemm_mfma_kernel<WT, KVT, MTv, NT, EPI, AL>), grid, block, lds, st, a)
-  const int ph = e->prof_begin(e->tag_gemm, st);
+  const int ph = e->prof_begin(e->tag_gemm[e->sid(st)], st);
   if (MT == 1) {
     if (aligned) DSM_LAUNCH(1, true); else DSM_LAUNCH(1, false);
   } else if (MT == 2) {

@@ -772,21 +772,31 @@ __global__ void lm_input_kernel(float* __restrict__ x, const uint16_t* __restric
                                 const uint32_t* __restrict__ text_token, const uint8_t* __restrict__ first_step,
                                 const uint8_t* __restrict__ active, int nc, int d, int audio_vocab,
                                 uint32_t pad_tok, uint32_t start_tok) {
+  // grid (B, d / 512): each thread sums 2 adjacent columns over the 1 + nc tables (independent 4-byte loads)
   const int b = blockIdx.x;
   __shared__ uint32_t toks[64];
   const bool first = first_step[b] != 0;
-  if (threadIdx.x < nc) {
-    uint32_t prev = next_cb[b * nc + threadIdx.x];
-    toks[threadIdx.x] = first ? pad_tok : prev;
-    if (active[b]) next_cb[b * nc + threadIdx.x] = codes[b * nc + threadIdx.x];
-  }
+  if (threadIdx.x < nc) toks[threadIdx.x] = first ? pad_tok : next_cb[b * nc + threadIdx.x];
   __syncthreads();
   const uint32_t tt = first ? start_tok : text_token[b];
-  for (int j = threadIdx.x; j < d; j += blockDim.x) {
-    float e = dsm_bf16_to_f32(text_emb[(long)tt * d + j]);
-    for (int i = 0; i < nc; ++i) e = e + dsm_bf16_to_f32(audio_emb[((long)i * audio_vocab + toks[i]) * d + j]);
-    x[(long)b * d + j] = e;
+  const int j = (blockIdx.y * blockDim.x + threadIdx.x) * 2;
+  if (j < d) {
+    uint32_t t2 = *reinterpret_cast<const uint32_t*>(text_emb + (long)tt * d + j);
+    float e0 = __uint_as_float(t2 << 16), e1 = __uint_as_float(t2 & 0xFFFF0000u);
+    for (int i = 0; i < nc; ++i) {  // emb = emb + e, in codebook order — core/lm.rs:988-993
+      uint32_t a2 = *reinterpret_cast<const uint32_t*>(audio_emb + ((long)i * audio_vocab + toks[i]) * d + j);
+      e0 = e0 + __uint_as_float(a2 << 16);
+      e1 = e1 + __uint_as_float(a2 & 0xFFFF0000u);
+    }
+    *reinterpret_cast<float2*>(x + (long)b * d + j) = make_float2(e0, e1);
   }
+}
+
+// next_codebooks = mask ? new codes : old (core/asr.rs:177-183); runs after lm_input_kernel consumed the old values
+__global__ void lm_next_codebooks_kernel(const uint32_t* __restrict__ codes, uint32_t* __restrict__ next_cb,
+                                         const uint8_t* __restrict__ active, int B, int nc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B * nc && active[i / nc]) next_cb[i] = codes[i];
 }
 
 // argmax over the text logits (first occurrence on ties, core/asr.rs:208-210) + item-state update
