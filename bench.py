@@ -224,6 +224,16 @@ def main():
         fill = ctx if not args.no_fill else min(it, ctx)
         # algorithmic bytes of ONE attention launch (one layer): K and V of every (slot, head) once + q in + out
         attn_bytes = B * H * (2 * fill * hd * kv_b + 2 * hd * 4)
+        # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (bench.py cannot run under --pmc and
+        # time itself): 2 x FETCH_SIZE (gfx950 counts 64 B per 128-B request) + WRITE_SIZE, per dispatch
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_hbm_traffic.json")))
+            for k in pmc["kernels"]:
+                if "attn_kernel<unsigned short, %d, 1>" % hd in k["kernel"] and args.config == "stt-1b-en_fr" and B == 64:
+                    traffic = (2 * k["FETCH_SIZE_KB_per_dispatch"] + k["WRITE_SIZE_KB_per_dispatch"]) * 1024
+        except Exception:
+            pass
         attn_us, attn_n = prof["attn_lm"]
         attn_avg_us = attn_us / max(attn_n, 1)
         achieved = attn_bytes / (attn_avg_us * 1e-6) / 1e9 if attn_n else 0.0
@@ -243,7 +253,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "attn_kernel<bf16,hd%d,T1> (LM ring-cache attention, %d launches/step)" % (hd, L),
                          "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "algorithmic_bytes_per_launch": attn_bytes, "avg_launch_us": attn_avg_us,
-                         "launches_timed": int(attn_n), "traffic": None,
+                         "launches_timed": int(attn_n), "traffic": traffic,
+                         "traffic_source": "profiles/r01/pmc_hbm_traffic.json (rocprofv3 --pmc, separate passes)" if traffic else None,
                          "isolated_single_stream": {"avg_launch_us": iso["attn_lm"][0] / max(iso["attn_lm"][1], 1),
                                                     "achieved": attn_bytes / (iso["attn_lm"][0] / max(iso["attn_lm"][1], 1) * 1e-6) / 1e9,
                                                     "frac": attn_bytes / (iso["attn_lm"][0] / max(iso["attn_lm"][1], 1) * 1e-6) / 1e9 / 8000.0}},

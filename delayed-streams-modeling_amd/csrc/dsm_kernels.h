@@ -440,6 +440,24 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs a) {
   }
 }
 
+// Ordered sum of `chunks` slab values at p, p + cstride, ...: loads are issued eight at a time, the adds stay
+// strictly left to right (canonical split-K order).
+__device__ __forceinline__ f32x4 slab_sum(const float* p, long cstride, int chunks) {
+  f32x4 t = *reinterpret_cast<const f32x4*>(p);
+  for (int c0 = 1; c0 < chunks; c0 += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int c = c0 + u < chunks ? c0 + u : chunks - 1;  // clamped duplicate load, discarded below
+      v[u] = *reinterpret_cast<const f32x4*>(p + c * cstride);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (c0 + u < chunks) t = t + v[u];
+  }
+  return t;
+}
+
 // Ordered split-K reduce + epilogue: one wave per 16x16 output tile (a gate/up tile pair for EPI_GATE).
 template <typename KVT, int EPI>
 __global__ __launch_bounds__(256) void gemm_reduce_kernel(GemmArgs a, int chunks) {
@@ -456,10 +474,7 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(GemmArgs a, int chunks
   f32x4 tot[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const float* p = a.ws + (long)m * ld + n + nt * a.nt_stride;
-    f32x4 v = *reinterpret_cast<const f32x4*>(p);
-    for (int c = 1; c < chunks; ++c) v = v + *reinterpret_cast<const f32x4*>(p + c * cstride);
-    tot[nt] = v;
+    tot[nt] = slab_sum(a.ws + (long)m * ld + n + nt * a.nt_stride, cstride, chunks);
   }
   if (EPI == EPI_GATE)
     epi_gate(a, tot[0], tot[NT - 1], m, n);
@@ -530,8 +545,7 @@ __global__ __launch_bounds__(256) void gemm_reduce_rows_kernel(GemmArgs a, int c
     const int i = it * 1024 + 4 * (int)threadIdx.x;
     v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < d) {
-      f32x4 t = *reinterpret_cast<const f32x4*>(p + i);
-      for (int c = 1; c < chunks; ++c) t = t + *reinterpret_cast<const f32x4*>(p + c * cstride + i);
+      f32x4 t = slab_sum(p + i, cstride, chunks);
       float o[4] = {t[0], t[1], t[2], t[3]};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-(kernel, grid) summary of a rocprofv3 kernel-trace CSV; also prints the inter-kernel idle time."""
-import collections, csv, glob, sys
-f = glob.glob(sys.argv[1] + "/*/*_kernel_trace.csv")[0]
+import collections, csv, glob, os, sys
+f = max(glob.glob(sys.argv[1] + "/*/*_kernel_trace.csv"), key=os.path.getmtime)
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 agg = collections.defaultdict(list)
 for r in rows:
