@@ -49,6 +49,22 @@ class AsrConfig(C.Structure):
         return out
 
 
+class TtsConfig(C.Structure):
+    """dsm_tts_config (include/dsm.h): lm::Config + DepFormerConfig + tts_streaming::Config."""
+    _fields_ = [
+        ("lm", TransformerConfig), ("text_in_vocab_size", C.c_int), ("text_out_vocab_size", C.c_int),
+        ("audio_vocab_size", C.c_int), ("audio_codebooks", C.c_int), ("depformer", TransformerConfig),
+        ("dep_num_slices", C.c_int), ("dep_low_rank", C.c_int), ("dep_weight_groups", C.c_int),
+        ("acoustic_delay", C.c_int), ("text_pad_token", C.c_int), ("text_bos_token", C.c_int),
+        ("text_eos_token", C.c_int), ("text_eop_token", C.c_int), ("text_start_token", C.c_int),
+        ("text_audio_delay_in_tokens", C.c_int), ("max_consecutive_pads", C.c_int), ("max_steps", C.c_int),
+        ("kv_bf16", C.c_int)]
+
+
+TTS_UNGENERATED = 0xFFFFFFFF
+TTS_ALLOW_PAD, TTS_ALLOW_PAD_OR_EPAD = -1, -2
+
+
 class AsrMsg(C.Structure):
     _fields_ = [("kind", C.c_int), ("batch_idx", C.c_int), ("step_idx", C.c_int), ("time", C.c_double),
                 ("tokens_offset", C.c_int), ("n_tokens", C.c_int), ("prs", C.c_float * MAX_EXTRA_HEADS)]
@@ -70,6 +86,8 @@ ABI_SYMBOLS = [
     "dsm_get_metrics", "dsm_batch_size", "dsm_n_q", "dsm_mimi_encode_step_dev", "dsm_asr_step_tokens_dev",
     "dsm_streams_join", "dsm_debug_read", "dsm_asr_step_pcm_dev", "dsm_prof_enable", "dsm_prof_read",
     "dsm_debug_set_positions", "dsm_mimi_decode_step", "dsm_mimi_decode_step_dev",
+    "dsm_tts_config_v202501", "dsm_tts_create", "dsm_tts_destroy", "dsm_tts_last_error", "dsm_tts_step",
+    "dsm_tts_audio_tokens", "dsm_tts_step_idx", "dsm_tts_reset_slot", "dsm_tts_debug_read",
 ]
 PROF_TAGS = ["attn_lm", "gemm_lm", "attn_mimi", "gemm_mimi", "rvq", "other"]
 
@@ -125,6 +143,21 @@ def load_library(path=None):
                  "dsm_n_q", "dsm_mimi_encode_step_dev", "dsm_asr_step_tokens_dev", "dsm_streams_join",
                  "dsm_debug_read", "dsm_asr_step_pcm_dev", "dsm_prof_enable", "dsm_prof_read"):
         getattr(lib, name).restype = C.c_int
+    lib.dsm_tts_config_v202501.argtypes = [C.POINTER(TtsConfig)]
+    lib.dsm_tts_config_v202501.restype = None
+    lib.dsm_tts_create.argtypes = [C.POINTER(TtsConfig), C.c_int, C.c_int, C.c_char_p, C.POINTER(vp)]
+    lib.dsm_tts_destroy.argtypes = [vp]
+    lib.dsm_tts_destroy.restype = None
+    lib.dsm_tts_last_error.argtypes = [vp]
+    lib.dsm_tts_last_error.restype = C.c_char_p
+    lib.dsm_tts_step.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.dsm_tts_audio_tokens.argtypes = [vp, C.c_int, C.c_int, vp]
+    lib.dsm_tts_step_idx.argtypes = [vp, C.c_int]
+    lib.dsm_tts_reset_slot.argtypes = [vp, C.c_int]
+    lib.dsm_tts_debug_read.argtypes = [vp, C.c_char_p, fp, C.c_size_t]
+    for name in ("dsm_tts_create", "dsm_tts_step", "dsm_tts_audio_tokens", "dsm_tts_step_idx", "dsm_tts_reset_slot",
+                 "dsm_tts_debug_read"):
+        getattr(lib, name).restype = C.c_int
     if path is None:
         _lib = lib
     return lib
@@ -166,6 +199,34 @@ def config_tiny(kv_bf16=1):
     mt.context, mt.max_period, mt.gating, mt.norm = 10, 10000, 0, 0
     mt.positional_embedding, mt.layer_scale, mt.conv_layout = 1, 1, 1
     m.quantizer_n_q, m.quantizer_bins, m.quantizer_dim, m.downsample_stride = 4, 32, 16, 2
+    return cfg
+
+
+def config_tts_v202501():
+    cfg = TtsConfig()
+    load_library().dsm_tts_config_v202501(C.byref(cfg))
+    return cfg
+
+
+def config_tts_tiny(kv_bf16=1):
+    """Small TTS configuration with every structural feature of the v202501 model: shared depformer with
+    fewer weight groups than slices, low-rank embeddings, acoustic and text-audio delays."""
+    cfg = TtsConfig()
+    t = cfg.lm
+    t.d_model, t.num_heads, t.num_layers, t.dim_feedforward = 128, 4, 2, 512
+    t.context, t.max_period, t.gating, t.norm = 16, 10000, 1, 1
+    t.positional_embedding, t.layer_scale, t.conv_layout = 1, 0, 0
+    cfg.text_in_vocab_size, cfg.text_out_vocab_size = 41, 40
+    cfg.audio_vocab_size, cfg.audio_codebooks = 33, 6
+    dp = cfg.depformer
+    dp.d_model, dp.num_heads, dp.num_layers, dp.dim_feedforward = 64, 2, 2, 192
+    dp.context, dp.max_period, dp.gating, dp.norm = 6, 10000, 1, 1
+    dp.positional_embedding, dp.layer_scale, dp.conv_layout = 0, 0, 0
+    cfg.dep_num_slices, cfg.dep_low_rank, cfg.dep_weight_groups = 6, 32, 3
+    cfg.acoustic_delay, cfg.text_pad_token, cfg.text_bos_token = 2, 3, 1
+    cfg.text_eos_token, cfg.text_eop_token, cfg.text_start_token = 2, 0, 40
+    cfg.text_audio_delay_in_tokens, cfg.max_consecutive_pads, cfg.max_steps = 3, 4, 64
+    cfg.kv_bf16 = kv_bf16
     return cfg
 
 
@@ -317,3 +378,60 @@ class AsrEngine:
         cnt = (C.c_uint64 * len(PROF_TAGS))()
         self._check(self.lib.dsm_prof_read(self.h, tot, cnt))
         return {t: (tot[i], cnt[i]) for i, t in enumerate(PROF_TAGS)}
+
+
+class TtsEngine:
+    """B independent tts_streaming::State generations behind the C ABI (core/tts_streaming.rs:117-242).
+    step() mirrors State::step(prev_text_token, allowed_tokens, conditions=None) with greedy sampling."""
+
+    def __init__(self, cfg, batch_size, lm_path, device_id=0):
+        self.lib = load_library()
+        self.cfg, self.B, self.S = cfg, batch_size, cfg.dep_num_slices
+        h = C.c_void_p()
+        rc = self.lib.dsm_tts_create(C.byref(cfg), device_id, batch_size, lm_path.encode(), C.byref(h))
+        if rc != 0:
+            msg = self.lib.dsm_tts_last_error(None)
+            raise DsmError(f"dsm_tts_create failed ({rc}): {msg.decode() if msg else '?'}")
+        self.h = h
+
+    def _check(self, rc):
+        if rc < 0:
+            msg = self.lib.dsm_tts_last_error(self.h)
+            raise DsmError(f"dsm error {rc}: {msg.decode() if msg else '?'}")
+        return rc
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.dsm_tts_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def step(self, prev_text_token, allowed, mask):
+        prev = np.ascontiguousarray(prev_text_token, dtype=np.uint32).reshape(self.B)
+        allowed = np.ascontiguousarray(allowed, dtype=np.int32).reshape(self.B)
+        mask = np.ascontiguousarray(mask, dtype=np.uint8).reshape(self.B)
+        text = np.zeros(self.B, dtype=np.uint32)
+        audio = np.zeros((self.B, self.S), dtype=np.uint32)
+        self._check(self.lib.dsm_tts_step(self.h, _ptr(prev), _ptr(allowed), _ptr(mask), _ptr(text), _ptr(audio)))
+        return text, audio
+
+    def audio_tokens(self, slot, step):
+        out = np.zeros(self.S, dtype=np.uint32)
+        self._check(self.lib.dsm_tts_audio_tokens(self.h, slot, step, _ptr(out)))
+        return out
+
+    def step_idx(self, slot):
+        return self._check(self.lib.dsm_tts_step_idx(self.h, slot))
+
+    def reset_batch_idx(self, slot):
+        self._check(self.lib.dsm_tts_reset_slot(self.h, slot))
+
+    def debug_read(self, name, n):
+        out = np.zeros(n, dtype=np.float32)
+        got = self._check(self.lib.dsm_tts_debug_read(self.h, name.encode(), _ptr(out), n))
+        return out[:got]

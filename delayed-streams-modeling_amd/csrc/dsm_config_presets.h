@@ -78,4 +78,22 @@ static inline void dsm_preset_stt_2_6b_en(dsm_asr_config* c) {
   c->extra_heads_dim = 0;
   c->asr_delay_in_tokens = 32;
 }
+
+/* tts_streaming::Config::v202501 (core/tts_streaming.rs:29-44) + configs/tts/config-tts.toml:35-79.  The toml's depformer
+ * transformer (num_heads = 11, head_dim = 1024 with d_model = 1024) cannot run in the reference (core/transformer.rs:538-541
+ * reshape fails); "11" is the number of weight groups.  A consistent shape is used instead:
+ * d 1024, 16 heads x 64, 4 layers, dim_feedforward 3072 (hidden 2048), 32 slices, low-rank 128, 11 weight groups. */
+static inline void dsm_preset_tts_v202501(dsm_tts_config* c) {
+  memset(c, 0, sizeof *c);
+  c->lm.d_model = 2048; c->lm.num_heads = 16; c->lm.num_layers = 16; c->lm.dim_feedforward = 8192;
+  c->lm.context = 1024; c->lm.max_period = 100000; c->lm.gating = 1; c->lm.norm = 1; c->lm.positional_embedding = 1;
+  c->text_in_vocab_size = 8001; c->text_out_vocab_size = 8000; c->audio_vocab_size = 2049; c->audio_codebooks = 32;
+  c->depformer.d_model = 1024; c->depformer.num_heads = 16; c->depformer.num_layers = 4; c->depformer.dim_feedforward = 3072;
+  c->depformer.context = 32; c->depformer.max_period = 10000; c->depformer.gating = 1; c->depformer.norm = 1;
+  c->depformer.positional_embedding = 0;
+  c->dep_num_slices = 32; c->dep_low_rank = 128; c->dep_weight_groups = 11;
+  c->acoustic_delay = 2; c->text_eop_token = 0; c->text_bos_token = 1; c->text_eos_token = 2; c->text_pad_token = 3;
+  c->text_start_token = 8000; c->text_audio_delay_in_tokens = 25; c->max_consecutive_pads = 10; c->max_steps = 4096;
+  c->kv_bf16 = 1;
+}
 #endif

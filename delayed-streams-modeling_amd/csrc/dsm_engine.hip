@@ -64,6 +64,7 @@ struct TransformerW {
   int hidden = 0;
   std::vector<TLayerW> layers;
   float* inv_freq = nullptr;
+  bool rope_pos_before = false;  // non-batched transformer semantics (TTS main LM)
 };
 
 struct TransformerState {  // per (side): ring caches + ScatteredCacheBuilder state
@@ -843,3 +844,4 @@ int run_conv(dsm_engine* e, hipStream_t st, const ConvGeom& c, const float* cat,
 }  // namespace
 
 #include "dsm_engine_api.inc"
+#include "dsm_tts.inc"

@@ -747,12 +747,16 @@ __global__ __launch_bounds__(256) void attn_kernel(float* __restrict__ out, cons
 __global__ void kv_builder_kernel(uint32_t* __restrict__ pos, uint32_t* __restrict__ idx,
                                   const uint8_t* __restrict__ active, uint32_t* __restrict__ start_pos,
                                   uint32_t* __restrict__ widx, float* __restrict__ rope_cs,
-                                  const float* __restrict__ inv_freq, int B, int T, int ctx, int hd) {
+                                  const float* __restrict__ inv_freq, int B, int T, int ctx, int hd,
+                                  int rope_before) {
+  // rope_before: the non-batched transformer rotates by current_seq_len BEFORE the append (core/transformer.rs:925-926);
+  // the batched one reads the builder's positions after indices_and_mask advanced them
   const int b = blockIdx.x;
   if (b >= B) return;
   __shared__ uint32_t s_pos_after;
   if (threadIdx.x == 0) {
     uint32_t p = pos[b], i = idx[b];
+    const uint32_t p0 = p;
     start_pos[b] = p;
     for (int t = 0; t < T; ++t) widx[b * T + t] = active[b] ? (uint32_t)((i + t) % ctx) : i;
     if (active[b]) {
@@ -760,7 +764,7 @@ __global__ void kv_builder_kernel(uint32_t* __restrict__ pos, uint32_t* __restri
       idx[b] = (uint32_t)((i + T) % ctx);
       p += T;
     }
-    s_pos_after = p;
+    s_pos_after = rope_before ? p0 : p;
   }
   __syncthreads();
   if (rope_cs) {
@@ -813,12 +817,8 @@ __global__ void lm_next_codebooks_kernel(const uint32_t* __restrict__ codes, uin
   if (i < B * nc && active[i / nc]) next_cb[i] = codes[i];
 }
 
-// argmax over the text logits (first occurrence on ties, core/asr.rs:208-210) + item-state update
-__global__ void lm_argmax_kernel(const float* __restrict__ logits, int V, uint32_t* __restrict__ text_out,
-                                 uint32_t* __restrict__ text_token, uint8_t* __restrict__ first_step,
-                                 const uint8_t* __restrict__ active) {
-  const int b = blockIdx.x;
-  const float* lg = logits + (long)b * V;
+// first-occurrence argmax of one row by a 256-thread block; valid in every thread after the call
+__device__ inline int block_argmax_first(const float* __restrict__ lg, int V) {
   float bv = -DSM_INF_F;
   int bi = 0x7FFFFFFF;
   for (int j = threadIdx.x; j < V; j += blockDim.x) {
@@ -841,13 +841,91 @@ __global__ void lm_argmax_kernel(const float* __restrict__ logits, int V, uint32
     }
     __syncthreads();
   }
+  const int r = si[0] == 0x7FFFFFFF ? 0 : si[0];  // all-NaN row: index 0, like a `>` scan from element 0
+  __syncthreads();
+  return r;
+}
+
+// argmax over the text logits (first occurrence on ties, core/asr.rs:208-210) + item-state update
+__global__ void lm_argmax_kernel(const float* __restrict__ logits, int V, uint32_t* __restrict__ text_out,
+                                 uint32_t* __restrict__ text_token, uint8_t* __restrict__ first_step,
+                                 const uint8_t* __restrict__ active) {
+  const int b = blockIdx.x;
+  const uint32_t tok = (uint32_t)block_argmax_first(logits + (long)b * V, V);
   if (threadIdx.x == 0) {
-    uint32_t tok = (uint32_t)si[0];
     text_out[b] = tok;
     if (active[b]) {
       text_token[b] = tok;
       first_step[b] = 0;
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// TTS glue — core/tts_streaming.rs:117-242, core/lm.rs:640-684, :983-995
+// ------------------------------------------------------------------------------------------
+// tokens [B][1+nc] int32: text token, then one entry per codebook; -1 = None ("literal zeros": the embedding is skipped)
+__global__ void tts_input_kernel(float* __restrict__ x, const uint16_t* __restrict__ text_emb,
+                                 const uint16_t* __restrict__ audio_emb /* [nc][audio_vocab][d] */,
+                                 const int32_t* __restrict__ tokens, int nc, int d, int audio_vocab) {
+  const int b = blockIdx.x;
+  __shared__ int32_t toks[72];
+  if ((int)threadIdx.x < 1 + nc) toks[threadIdx.x] = tokens[b * (1 + nc) + threadIdx.x];
+  __syncthreads();
+  const int j = (blockIdx.y * blockDim.x + threadIdx.x) * 2;
+  if (j < d) {
+    uint32_t t2 = *reinterpret_cast<const uint32_t*>(text_emb + (long)toks[0] * d + j);
+    float e0 = __uint_as_float(t2 << 16), e1 = __uint_as_float(t2 & 0xFFFF0000u);
+    for (int i = 0; i < nc; ++i) {
+      const int32_t t = toks[1 + i];
+      if (t < 0) continue;
+      uint32_t a2 = *reinterpret_cast<const uint32_t*>(audio_emb + ((long)i * audio_vocab + t) * d + j);
+      e0 = e0 + __uint_as_float(a2 << 16);
+      e1 = e1 + __uint_as_float(a2 & 0xFFFF0000u);
+    }
+    *reinterpret_cast<float2*>(x + (long)b * d + j) = make_float2(e0, e1);
+  }
+}
+
+// text-token rule of State::step (:178-197).  allowed >= 0: Text(v); -1: Pad; -2: PadOrEpad (argmax of the text
+// logits decides pad vs end-of-pad unless force_eop, i.e. consecutive_pads > max_consecutive_pads)
+__global__ void tts_text_token_kernel(const float* __restrict__ logits, int V, const int32_t* __restrict__ allowed,
+                                      const uint8_t* __restrict__ force_eop, uint32_t pad, uint32_t eop,
+                                      uint32_t* __restrict__ text_token, uint32_t* __restrict__ last_tok) {
+  const int b = blockIdx.x;
+  const int32_t al = allowed[b];
+  uint32_t tok;
+  if (al >= 0) tok = (uint32_t)al;
+  else if (al == -1) tok = pad;
+  else if (force_eop[b]) tok = eop;
+  else tok = ((uint32_t)block_argmax_first(logits + (long)b * V, V) == pad) ? pad : eop;  // block-uniform branch
+  if (threadIdx.x == 0) {
+    text_token[b] = tok;
+    last_tok[b] = tok;
+  }
+}
+
+// e[b] = table[last_tok[b]] (LowRankEmbeddings::forward with the low-rank product folded into the table at load)
+__global__ void dep_gather_kernel(float* __restrict__ e, const float* __restrict__ table,
+                                  const uint32_t* __restrict__ last_tok, int vocab, int D) {
+  const int b = blockIdx.x;
+  uint32_t t = last_tok[b];
+  if (t >= (uint32_t)vocab) t = 0;
+  const float4* src = reinterpret_cast<const float4*>(table + (long)t * D);
+  float4* dst = reinterpret_cast<float4*>(e + (long)b * D);
+  for (int j = threadIdx.x; j < D / 4; j += blockDim.x) dst[j] = src[j];
+}
+
+// DepFormer::sample slice epilogue: ArgMax sample, forced pre-delay pad for the NEXT slice's input (:671-680)
+__global__ void dep_argmax_kernel(const float* __restrict__ logits, int V, int k, int S, uint32_t* __restrict__ lat,
+                                  uint32_t* __restrict__ last_tok, const uint8_t* __restrict__ run,
+                                  const uint8_t* __restrict__ forced, uint32_t pad) {
+  const int b = blockIdx.x;
+  if (!run[b]) return;
+  const uint32_t tok = (uint32_t)block_argmax_first(logits + (long)b * V, V);
+  if (threadIdx.x == 0) {
+    lat[(long)b * S + k] = tok;
+    last_tok[b] = (forced[b] && k > 0) ? pad : tok;
   }
 }
 

@@ -135,6 +135,50 @@ def lm_spec(cfg):
     return s
 
 
+def tts_spec(cfg):
+    """TTS checkpoint keys (core/lm.rs:501-590): main LM + shared depformer with per-group gating/linear_in."""
+    s = Spec()
+    t, dp = cfg.lm, cfg.depformer
+    d, D, S, G, lr = t.d_model, dp.d_model, cfg.dep_num_slices, cfg.dep_weight_groups, cfg.dep_low_rank
+    s.add("text_emb.weight", (cfg.text_in_vocab_size, d), "normal", 0.3)
+    for i in range(cfg.audio_codebooks):
+        s.add(f"emb.{i}.weight", (cfg.audio_vocab_size, d), "normal", 0.3)
+    _transformer_spec(s, "transformer", t, gating_hidden(t))
+    s.add("out_norm.alpha", (1, 1, d), "alpha")
+    s.add("text_linear.weight", (cfg.text_out_vocab_size, d), "normal", d ** -0.5)
+    for g in range(G):
+        s.add(f"depformer_in.{g}.weight", (D, d), "normal", d ** -0.5)
+    w = lr if lr > 0 else D
+    s.add("depformer_text_emb.weight", (cfg.text_in_vocab_size, w), "normal", 0.5)
+    if lr > 0:
+        s.add("depformer_text_emb.low_rank.weight", (D, lr), "normal", lr ** -0.5)
+    for k in range(S - 1):
+        s.add(f"depformer_emb.{k}.weight", (cfg.audio_vocab_size, w), "normal", 0.5)
+        if lr > 0:
+            s.add(f"depformer_emb.{k}.low_rank.weight", (D, lr), "normal", lr ** -0.5)
+    for k in range(S):
+        s.add(f"linears.{k}.weight", (cfg.audio_vocab_size - 1, D), "normal", D ** -0.5)
+    hid = gating_hidden(dp)
+    for l in range(dp.num_layers):
+        p = f"depformer.layers.{l}"
+        s.add(f"{p}.self_attn.in_proj_weight", (3 * D, D), "normal", D ** -0.5)
+        s.add(f"{p}.self_attn.out_proj.weight", (D, D), "normal", D ** -0.5)
+        s.add(f"{p}.norm1.alpha", (1, 1, D), "alpha")
+        s.add(f"{p}.norm2.alpha", (1, 1, D), "alpha")
+        for g in range(G):
+            s.add(f"{p}.gating.{g}.linear_in.weight", (2 * hid, D), "normal", D ** -0.5)
+            s.add(f"{p}.gating.{g}.linear_out.weight", (D, hid), "normal", hid ** -0.5)
+    return s
+
+
+def make_synth_tts_weights(cfg, out_dir, seed=SEED, tag="tts"):
+    os.makedirs(out_dir, exist_ok=True)
+    path = os.path.join(out_dir, f"{tag}.lm.safetensors")
+    if not os.path.exists(path):
+        write_safetensors(path, tts_spec(cfg), "BF16", seed)
+    return path
+
+
 def _conv(s, prefix, out_c, in_c, k, bias=True):
     s.add(f"{prefix}.conv.conv.weight", (out_c, in_c, k), "normal", (in_c * k) ** -0.5)
     if bias:

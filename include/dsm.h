@@ -214,6 +214,45 @@ enum { DSM_PROF_ATTN_LM = 0, DSM_PROF_GEMM_LM = 1, DSM_PROF_ATTN_MIMI = 2, DSM_P
 int dsm_prof_enable(dsm_engine*, unsigned tag_mask);
 int dsm_prof_read(dsm_engine*, double* total_us /*[DSM_PROF_NTAGS]*/, uint64_t* launches /*[DSM_PROF_NTAGS]*/);
 
+/* ------------------------------------------------------------------------------------------------
+ * TTS (BASELINE.json configs[4]): tts_streaming::State::step + LmModel::forward_cond + DepFormer::sample
+ * (core/tts_streaming.rs:117-242, core/lm.rs:957-1008, :640-684), greedy sampling only — the reference
+ * selects Sampling::ArgMax when temperature <= 0 (srv/tts.rs:402).  The reference serves one generation at a
+ * time behind a mutex (srv/tts.rs:374); here B independent generations advance together, each slot with its
+ * own step index (batching the TTS path is new capability).
+ * ------------------------------------------------------------------------------------------------ */
+#define DSM_TTS_UNGENERATED 0xFFFFFFFFu /* tts_streaming::UNGENERATED */
+enum { DSM_TTS_ALLOW_PAD = -1, DSM_TTS_ALLOW_PAD_OR_EPAD = -2 }; /* AllowedTokens::{Pad, PadOrEpad}; >= 0: Text(v) */
+
+typedef struct dsm_tts_config {
+  dsm_transformer_config lm;        /* [modules.tts.model.transformer] */
+  int text_in_vocab_size, text_out_vocab_size, audio_vocab_size, audio_codebooks;
+  dsm_transformer_config depformer; /* [modules.tts.model.depformer.transformer]; positional_embedding = None */
+  int dep_num_slices;               /* DepFormerConfig::num_slices = generated audio codebooks */
+  int dep_low_rank;                 /* low_rank_embeddings (0 = full-rank tables) */
+  int dep_weight_groups;            /* distinct linear_in / gating weight sets: idx*groups/num_slices (core/lm.rs:527,558) */
+  /* tts_streaming::Config — core/tts_streaming.rs:12-44 */
+  int acoustic_delay, text_pad_token, text_bos_token, text_eos_token, text_eop_token, text_start_token;
+  int text_audio_delay_in_tokens, max_consecutive_pads, max_steps;
+  int kv_bf16;
+} dsm_tts_config;
+void dsm_tts_config_v202501(dsm_tts_config* out); /* Config::v202501 + configs/tts/config-tts.toml with a consistent depformer */
+
+typedef struct dsm_tts dsm_tts;
+int dsm_tts_create(const dsm_tts_config* cfg, int device_id, int batch_size, const char* lm_safetensors, dsm_tts** out);
+void dsm_tts_destroy(dsm_tts*);
+const char* dsm_tts_last_error(const dsm_tts*);
+/* State::step for every active slot.  prev_text_token [B]; allowed [B] (>= 0 Text(v), DSM_TTS_ALLOW_*);
+ * text_token_out [B]; audio_out [B*num_slices]: this step's last_audio_tokens (depformer samples) or
+ * DSM_TTS_UNGENERATED while step_idx < text_audio_delay_in_tokens.  */
+int dsm_tts_step(dsm_tts*, const uint32_t* prev_text_token, const int32_t* allowed, const uint8_t* mask,
+                 uint32_t* text_token_out, uint32_t* audio_out);
+/* audio_tokens[step] of a slot (delayed write-back applied, core/tts_streaming.rs:220-236); entries may be UNGENERATED */
+int dsm_tts_audio_tokens(dsm_tts*, int slot, int step, uint32_t* out /* [num_slices] */);
+int dsm_tts_step_idx(dsm_tts*, int slot);
+int dsm_tts_reset_slot(dsm_tts*, int slot);
+int dsm_tts_debug_read(dsm_tts*, const char* name, float* out, size_t cap); /* "lm.hidden", "lm.logits" */
+
 /* Profiling aid: pretend every slot already streamed `pos` frames (ring index = pos mod ctx, cache content
  * untouched) so that short profiler runs see steady-state attention traffic.  Never used for `value`. */
 int dsm_debug_set_positions(dsm_engine*, uint32_t lm_pos, uint32_t mimi_pos);

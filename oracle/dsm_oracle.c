@@ -1031,6 +1031,7 @@ typedef struct {
   dsm_transformer_config cfg;
   int B, hidden; /* gating hidden size */
   int kv_bf16;
+  int rope_pos_before; /* 1: non-batched transformer::StreamingTransformer — pos = current_seq_len (core/transformer.rs:925-926) */
   orc_tlayer* layers;
   orc_kvb* builder;
   float* inv_freq;
@@ -1111,6 +1112,8 @@ static void transformer_forward(orc_transformer* tr, float* xs, int T, const uin
   const int B = tr->B, d = c->d_model, H = c->num_heads, hd = d / H, ctx = c->context;
   uint32_t* indices = (uint32_t*)xmalloc(sizeof(uint32_t) * (size_t)B * T);
   float* maskf = (float*)xmalloc(sizeof(float) * (size_t)B * T * ctx);
+  uint32_t* pos_before = (uint32_t*)xmalloc(sizeof(uint32_t) * (size_t)B);
+  memcpy(pos_before, tr->builder->positions, sizeof(uint32_t) * (size_t)B);
   orc_kvb_indices_and_mask(tr->builder, T, mask, indices, maskf); /* :438-441 */
   /* rope positions are read AFTER the builder advanced them — :442-450 */
   const uint32_t* positions = tr->builder->positions;
@@ -1130,7 +1133,7 @@ static void transformer_forward(orc_transformer* tr, float* xs, int T, const uin
     for (int b = 0; b < B; ++b) {
       for (int t = 0; t < T; ++t) {
         float* row = qkv + ((size_t)b * T + t) * 3 * d;
-        uint32_t pos = positions[b] + (uint32_t)t;
+        uint32_t pos = (tr->rope_pos_before ? pos_before[b] : positions[b]) + (uint32_t)t;
         for (int h = 0; h < H; ++h) {
           if (c->positional_embedding == 1) {
             orc_rope_apply(row + (size_t)h * hd, hd, tr->inv_freq, pos);         /* q */
@@ -1190,7 +1193,7 @@ static void transformer_forward(orc_transformer* tr, float* xs, int T, const uin
         xs[i * d + j] = xs[i * d + j] + v;
       }
   }
-  free(indices); free(maskf); free(nrm); free(qkv); free(att); free(prj); free(hid); free(act);
+  free(indices); free(maskf); free(nrm); free(qkv); free(att); free(prj); free(hid); free(act); free(pos_before);
 }
 
 /* ======================================================================================
@@ -1732,3 +1735,5 @@ float orc_gelu_erf(float x) { return dsm_gelu_erf(x); }
 void orc_sincosf(float x, float* s, float* c) { dsm_sincosf(x, s, c); }
 uint16_t orc_f32_to_bf16(float x) { return dsm_f32_to_bf16(x); }
 float orc_bf16_to_f32(uint16_t h) { return dsm_bf16_to_f32(h); }
+
+#include "dsm_oracle_tts.inc"

@@ -98,3 +98,20 @@ float orc_bf16_to_f32(uint16_t h);
 #ifdef __cplusplus
 }
 #endif
+
+/* ---- TTS step (config 5): see oracle/dsm_oracle_tts.inc ---- */
+#ifdef __cplusplus
+extern "C" {
+#endif
+typedef struct orc_tts orc_tts;
+orc_tts* orc_tts_create(const dsm_tts_config* cfg, int batch_size, const char* lm_safetensors, char* err, size_t errcap);
+void orc_tts_destroy(orc_tts*);
+int orc_tts_step(orc_tts*, const uint32_t* prev_text_token, const int32_t* allowed, const uint8_t* mask,
+                 uint32_t* text_token_out, uint32_t* audio_out);
+int orc_tts_audio_tokens(orc_tts*, int slot, int step, uint32_t* out);
+int orc_tts_step_idx(orc_tts*, int slot);
+int orc_tts_reset_slot(orc_tts*, int slot);
+int orc_tts_debug_read(orc_tts*, const char* name, float* out, size_t cap);
+#ifdef __cplusplus
+}
+#endif

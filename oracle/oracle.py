@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 
 import dsm_amd  # noqa: F401  (registers the package)
-from dsm_amd import AsrConfig, AsrMsg, FRAME_SIZE, MSG_WORD, MSG_END_WORD
+from dsm_amd import AsrConfig, AsrMsg, TtsConfig, FRAME_SIZE, MSG_WORD, MSG_END_WORD
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(_HERE, "libdsm_oracle.so")
@@ -80,6 +80,15 @@ def lib():
         L.orc_convtr1d_forward.argtypes = [vp, vp, C.c_int, vp, C.c_int]
         L.orc_convtr1d_reset_batch_idx.argtypes = [vp, C.c_int]
         L.orc_convtr1d_reset_batch_idx.restype = None
+        L.orc_tts_create.argtypes = [C.POINTER(TtsConfig), C.c_int, C.c_char_p, C.c_char_p, C.c_size_t]
+        L.orc_tts_create.restype = vp
+        L.orc_tts_destroy.argtypes = [vp]
+        L.orc_tts_destroy.restype = None
+        L.orc_tts_step.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.orc_tts_audio_tokens.argtypes = [vp, C.c_int, C.c_int, vp]
+        L.orc_tts_step_idx.argtypes = [vp, C.c_int]
+        L.orc_tts_reset_slot.argtypes = [vp, C.c_int]
+        L.orc_tts_debug_read.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
         _lib = L
     return _lib
 
@@ -166,6 +175,58 @@ class OracleAsr:
     def debug_read(self, name, n):
         out = np.zeros(n, dtype=np.float32)
         got = self.L.orc_debug_read(self.h, name.encode(), p(out), n)
+        if got < 0:
+            raise KeyError(name)
+        return out[:got]
+
+
+class OracleTts:
+    """Same surface as dsm_amd.TtsEngine, computed by the CPU restatement (oracle/dsm_oracle_tts.inc)."""
+
+    def __init__(self, cfg, batch_size, lm_path):
+        self.L = lib()
+        self.cfg, self.B, self.S = cfg, batch_size, cfg.dep_num_slices
+        err = C.create_string_buffer(512)
+        self.h = self.L.orc_tts_create(C.byref(cfg), batch_size, lm_path.encode(), err, 512)
+        if not self.h:
+            raise RuntimeError("oracle create failed: " + err.value.decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.orc_tts_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def step(self, prev_text_token, allowed, mask):
+        prev = np.ascontiguousarray(prev_text_token, dtype=np.uint32).reshape(self.B)
+        allowed = np.ascontiguousarray(allowed, dtype=np.int32).reshape(self.B)
+        mask = np.ascontiguousarray(mask, dtype=np.uint8).reshape(self.B)
+        text = np.zeros(self.B, dtype=np.uint32)
+        audio = np.zeros((self.B, self.S), dtype=np.uint32)
+        rc = self.L.orc_tts_step(self.h, p(prev), p(allowed), p(mask), p(text), p(audio))
+        if rc < 0:
+            raise RuntimeError(f"oracle tts step failed ({rc})")
+        return text, audio
+
+    def audio_tokens(self, slot, step):
+        out = np.zeros(self.S, dtype=np.uint32)
+        self.L.orc_tts_audio_tokens(self.h, slot, step, p(out))
+        return out
+
+    def step_idx(self, slot):
+        return self.L.orc_tts_step_idx(self.h, slot)
+
+    def reset_batch_idx(self, slot):
+        self.L.orc_tts_reset_slot(self.h, slot)
+
+    def debug_read(self, name, n):
+        out = np.zeros(n, dtype=np.float32)
+        got = self.L.orc_tts_debug_read(self.h, name.encode(), p(out), n)
         if got < 0:
             raise KeyError(name)
         return out[:got]

@@ -1,0 +1,83 @@
+"""GPU parity of the TTS step (tts_streaming::State::step + LmModel::forward_cond + DepFormer::sample, greedy) through
+the C ABI against the oracle: every emitted token and every audio_tokens table entry must be identical."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tts_schedule import run, schedule
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def tts(dsm):
+    from dsm_amd import synth
+    cfg = dsm.config_tts_tiny()
+    return cfg, synth.make_synth_tts_weights(cfg, os.environ.get("DSM_WEIGHTS_DIR", "/tmp/dsm_weights"), tag="tts_tiny")
+
+
+def _compare(dsm, orc, cfg, path, B, steps, resets=None):
+    eng = dsm.TtsEngine(cfg, B, path)
+    ora = orc.OracleTts(cfg, B, path)
+    resets = resets or {}
+    for s, (prev, allowed, mask) in enumerate(schedule(cfg, B, steps)):
+        for slot in resets.get(s, []):
+            eng.reset_batch_idx(slot)
+            ora.reset_batch_idx(slot)
+        te, ae = eng.step(prev, allowed, mask)
+        to, ao = ora.step(prev, allowed, mask)
+        act = mask.astype(bool)
+        n = B * cfg.lm.d_model
+        he, ho = eng.debug_read("lm.hidden", n).reshape(B, -1), ora.debug_read("lm.hidden", n).reshape(B, -1)
+        assert np.array_equal(he[act].view(np.uint32), ho[act].view(np.uint32)), f"LM hidden bits differ at step {s}"
+        assert np.array_equal(te[act], to[act]), f"text tokens differ at step {s}"
+        assert np.array_equal(ae[act], ao[act]), f"depformer tokens differ at step {s}: {ae[act]} vs {ao[act]}"
+    for b in range(B):
+        assert eng.step_idx(b) == ora.step_idx(b)
+        for i in range(eng.step_idx(b)):
+            assert np.array_equal(eng.audio_tokens(b, i), ora.audio_tokens(b, i))
+    eng.close()
+    ora.close()
+
+
+@pytest.mark.parametrize("kv_bf16", [1, 0])
+def test_tts_tiny_parity(gpu, dsm, lib, orc, tts, kv_bf16):
+    cfg, path = tts
+    c = dsm.TtsConfig.from_buffer_copy(cfg)
+    c.kv_bf16 = kv_bf16
+    _compare(dsm, orc, c, path, 4, 24, resets={9: [2], 15: [0, 3]})
+
+
+def test_tts_ring_wrap(gpu, dsm, lib, orc, tts):
+    """Main-LM context is 16: 40 steps wrap the ring cache more than twice."""
+    cfg, path = tts
+    _compare(dsm, orc, cfg, path, 2, 40)
+
+
+def test_tts_committed_trace(gpu, dsm, lib, tts):
+    cfg, path = tts
+    with open(os.path.join(HERE, "golden", "tiny_tts.json")) as f:
+        gold = json.load(f)
+    eng = dsm.TtsEngine(cfg, gold["B"], path)
+    trace, tables = run(eng, cfg, gold["B"], gold["steps"], resets={int(k): v for k, v in gold["resets"].items()})
+    eng.close()
+    assert [t.tolist() for t, _ in trace] == gold["text"]
+    assert [a.tolist() for _, a in trace] == gold["audio"]
+    assert [[r.tolist() for r in tab] for tab in tables] == gold["tables"]
+
+
+def test_tts_errors(gpu, dsm, lib, tts):
+    cfg, path = tts
+    small = dsm.TtsConfig.from_buffer_copy(cfg)
+    small.max_steps = 4
+    eng = dsm.TtsEngine(small, 1, path)
+    for s in range(small.max_steps + small.acoustic_delay - 1):
+        eng.step([1], [9], [1])
+    with pytest.raises(dsm.DsmError, match="max step-idx"):
+        eng.step([1], [9], [1])
+    eng.close()
+    with pytest.raises(dsm.DsmError):
+        dsm.TtsEngine(cfg, 1, path + ".missing")

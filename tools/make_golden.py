@@ -49,8 +49,32 @@ def run(make_engine, mimi_reset):
     return out
 
 
+def run_tts():
+    """tests/golden/tiny_tts.json: oracle trace of tests/tts_schedule.run on config_tts_tiny."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dsm_amd
+    import oracle
+    from dsm_amd import synth
+    from tts_schedule import run as tts_run
+    cfg = dsm_amd.config_tts_tiny()
+    path = synth.make_synth_tts_weights(cfg, os.environ.get("DSM_WEIGHTS_DIR", "/tmp/dsm_weights"), tag="tts_tiny")
+    b, steps, resets = 4, 20, {8: [1], 13: [0, 3]}
+    o = oracle.OracleTts(cfg, b, path)
+    trace, tables = tts_run(o, cfg, b, steps, resets=resets)
+    gold = {"B": b, "steps": steps, "resets": {str(k): v for k, v in resets.items()},
+            "text": [t.tolist() for t, _ in trace], "audio": [a.tolist() for _, a in trace],
+            "tables": [[r.tolist() for r in tab] for tab in tables]}
+    out = os.path.join(ROOT, "tests", "golden", "tiny_tts.json")
+    with open(out, "w") as f:
+        json.dump(gold, f, separators=(",", ":"))
+    print("wrote", out, os.path.getsize(out), "bytes")
+
+
 if __name__ == "__main__":
     import oracle
+    if "--tts" in sys.argv:
+        run_tts()
+        sys.exit(0)
     res = run(oracle.OracleAsr, lambda e, slot: e.mimi_reset_batch_idx(slot, side=0))
     path = os.path.join(ROOT, "tests", "golden", "tiny_asr.json")
     with open(path, "w") as f:
