@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64, help="stream slots per GPU")
     ap.add_argument("--config", default="stt-1b-en_fr", choices=["stt-1b-en_fr", "stt-2.6b-en", "tiny"])
-    ap.add_argument("--workload", default="stt", choices=["stt", "mimi-decode"],
+    ap.add_argument("--workload", default="stt", choices=["stt", "mimi-decode", "tts"],
                     help="stt = Mimi encode + LM decode (the headline metric); mimi-decode = Mimi::decode_step only (config 5)")
     ap.add_argument("--no-fill", action="store_true", help="skip the untimed ring-cache fill (debug only)")
     ap.add_argument("--fast-fill", action="store_true",
@@ -102,6 +102,53 @@ def bench_decode(args, eng, cfg, B, dev, world, rank, dist, torch):
     eng.close()
 
 
+def bench_tts(args, world, rank, local_rank):
+    """BASELINE.json configs[4], LM side: tts_streaming::State::step (main LM + 32-slice depformer, greedy) for B
+    generations per 80 ms frame.  Host-pointer ABI (the step's inputs are B tokens); every step synchronises, as the
+    reference's does when it reads the sampled tokens back."""
+    import torch
+    import dsm_amd
+    from dsm_amd import synth
+    cfg = dsm_amd.config_tts_v202501()
+    B = args.batch
+    path = synth.make_synth_tts_weights(cfg, args.weights_dir, tag="tts-v202501" + ("" if world == 1 else f".rank{rank}"))
+    eng = dsm_amd.TtsEngine(cfg, B, path, device_id=local_rank)
+    if world > 1:
+        os.remove(path)
+    rng = np.random.default_rng(3 + rank)
+    mask = np.ones(B, dtype=np.uint8)
+    fill = cfg.text_audio_delay_in_tokens + cfg.acoustic_delay + 3  # past both delay windows: every codebook feeds back
+
+    def step():
+        prev = rng.integers(4, cfg.text_in_vocab_size - 1, B).astype(np.uint32)
+        allowed = rng.integers(4, cfg.text_in_vocab_size - 1, B).astype(np.int32)
+        eng.step(prev, allowed, mask)
+
+    for _ in range(fill + args.warmup):
+        step()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=torch.device("cuda", local_rank))
+    if world > 1:
+        dist.barrier()
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    ms = float(dt.item()) / args.steps * 1000
+    if rank == 0:
+        print(json.dumps({"metric": "TTS step real-time generation throughput @ bs=%d" % B, "value": world * B * 0.08 / (ms / 1000),
+                          "unit": "x realtime (seconds of audio tokens per wall second)", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "f32 accumulate, bf16 weights", "data": "synthetic", "rtf": 80.0 / ms,
+                          "config": {"workload": "tts v202501 State::step (2048-d x 16 LM + 32-slice depformer, greedy), batch=%d, "
+                                                 "KV fill %d frames" % (B, fill + args.warmup)}}))
+    eng.close()
+
+
 def main():
     args = parse()
     import torch
@@ -119,6 +166,8 @@ def main():
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if args.workload == "tts":
+        return bench_tts(args, world, rank, local_rank)
 
     cfg = {"stt-1b-en_fr": dsm_amd.config_stt_1b_en_fr, "stt-2.6b-en": dsm_amd.config_stt_2_6b_en,
            "tiny": dsm_amd.config_tiny}[args.config]()

@@ -70,3 +70,36 @@ def test_stt_2_6b_en_shapes(gpu, dsm, lib, orc):
     ora.close()
     for p in (lm,):  # 5 GB: do not leave it in /tmp for the next test session
         os.remove(p)
+
+
+def test_tts_v202501_shapes(gpu, dsm, lib, orc):
+    """BASELINE.json configs[4] shapes: 2048-d x 16-layer main LM (32 input codebooks), depformer 1024-d x 4 layers over
+    32 slices with 11 weight groups and rank-128 embeddings.  text_audio_delay_in_tokens is shortened (25 -> 3) so that
+    ten steps reach the phase where every codebook feeds back generated tokens."""
+    import os
+    from dsm_amd import synth
+    cfg = dsm.config_tts_v202501()
+    cfg.text_audio_delay_in_tokens, cfg.max_steps = 3, 64
+    path = synth.make_synth_tts_weights(cfg, os.environ.get("DSM_WEIGHTS_DIR", "/tmp/dsm_weights"), tag="tts-v202501")
+    B = 2
+    eng = dsm.TtsEngine(cfg, B, path)
+    ora = orc.OracleTts(cfg, B, path)
+    rng = np.random.default_rng(2)
+    for s in range(10):
+        prev = rng.integers(0, cfg.text_in_vocab_size, B).astype(np.uint32)
+        allowed = np.array([int(rng.integers(4, 8000)), dsm.TTS_ALLOW_PAD_OR_EPAD], dtype=np.int32)
+        mask = np.array([1, 0 if s == 4 else 1], dtype=np.uint8)
+        act = mask.astype(bool)
+        te, ae = eng.step(prev, allowed, mask)
+        to, ao = ora.step(prev, allowed, mask)
+        he = eng.debug_read("lm.hidden", B * cfg.lm.d_model).reshape(B, -1)
+        ho = ora.debug_read("lm.hidden", B * cfg.lm.d_model).reshape(B, -1)
+        assert np.array_equal(he[act].view(np.uint32), ho[act].view(np.uint32)), f"LM hidden differs at step {s}"
+        assert np.array_equal(te[act], to[act]), f"text tokens differ at step {s}"
+        assert np.array_equal(ae[act], ao[act]), f"depformer tokens differ at step {s}"
+    for b in range(B):
+        for i in range(eng.step_idx(b)):
+            assert np.array_equal(eng.audio_tokens(b, i), ora.audio_tokens(b, i))
+    eng.close()
+    ora.close()
+    os.remove(path)
