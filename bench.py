@@ -237,6 +237,7 @@ def main():
     # ---- timed region: exactly K steps, dominant kernel bracketed by HIP events on its own stream ----
     eng.prof_enable(["attn_lm"])
     eng.prof_read()
+    eng.prof_read_device()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -245,6 +246,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     prof = eng.prof_read()
+    prof_dev = eng.prof_read_device()
     eng.prof_enable([])
     dt_t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -257,35 +259,51 @@ def main():
     overlap = not args.no_overlap
     args.no_overlap = True
     torch.cuda.synchronize()
+    eng.debug_serialize_groups(True)  # stream groups one after the other: nothing overlaps in this pass
     eng.prof_enable(dsm_amd.PROF_TAGS)
     eng.prof_read()
+    eng.prof_read_device()
     for _ in range(5):
         step(it)
         it += 1
     iso = eng.prof_read()
+    iso_dev = eng.prof_read_device()
     breakdown = {k: round(v[0] / 5.0, 1) for k, v in iso.items()}
     eng.prof_enable([])
+    eng.debug_serialize_groups(False)
     args.no_overlap = not overlap
+    groups = eng.stream_groups()
 
     if rank == 0:
         H, hd, L = cfg.lm.num_heads, cfg.lm.d_model // cfg.lm.num_heads, cfg.lm.num_layers
         kv_b = 2 if cfg.kv_bf16 else 4
         fill = ctx if not args.no_fill else min(it, ctx)
-        # algorithmic bytes of ONE attention launch (one layer): K and V of every (slot, head) once + q in + out
-        attn_bytes = B * H * (2 * fill * hd * kv_b + 2 * hd * 4)
+        # algorithmic bytes of the attention launches of ONE layer: K and V of every (slot, head) once + q in + out.
+        # The LM step runs the batch as len(groups) stream groups, each with its own attention launch per layer, so a
+        # launch covers B / len(groups) slots on average and `achieved` is bytes of all timed launches / their time.
+        attn_bytes_layer = B * H * (2 * fill * hd * kv_b + 2 * hd * 4)
+        attn_bytes = attn_bytes_layer / len(groups)
         # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (bench.py cannot run under --pmc and
         # time itself): 2 x FETCH_SIZE (gfx950 counts 64 B per 128-B request) + WRITE_SIZE, per dispatch
         traffic = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_hbm_traffic.json")))
             for k in pmc["kernels"]:
-                if "attn_kernel<unsigned short, %d, 1>" % hd in k["kernel"] and args.config == "stt-1b-en_fr" and B == 64:
+                if ("attn_kernel<unsigned short, %d, 1>" % hd in k["kernel"] and args.config == "stt-1b-en_fr"
+                        and B == 64 and k.get("slots_per_dispatch", 64) * len(groups) == B):
                     traffic = (2 * k["FETCH_SIZE_KB_per_dispatch"] + k["WRITE_SIZE_KB_per_dispatch"]) * 1024
         except Exception:
             pass
-        attn_us, attn_n = prof["attn_lm"]
+        m = eng.metrics()
+        step_bytes = m.algorithmic_bytes_lm + m.algorithmic_bytes_encode
+        # launch duration = in-kernel device-clock bracket (first workgroup in -> last out), the quantity rocprofv3's
+        # kernel trace reports; the HIP-event bracket on the launching stream is kept beside it: with three streams in
+        # flight it also contains the time the launch queues behind the other streams' kernels
+        attn_us, attn_n = prof_dev["attn_lm"]
         attn_avg_us = attn_us / max(attn_n, 1)
+        ev_us, ev_n = prof["attn_lm"]
         achieved = attn_bytes / (attn_avg_us * 1e-6) / 1e9 if attn_n else 0.0
+        iso_avg_us = iso_dev["attn_lm"][0] / max(iso_dev["attn_lm"][1], 1)
         out = {
             "metric": "real-time stream throughput, %s @ bs=%d per GPU (Mimi encode + LM decode per 80 ms frame)" % (args.config, B),
             "value": world * B * 0.08 / (ms_per_step / 1000.0),
@@ -297,17 +315,21 @@ def main():
             "config": {"workload": "%s batch=%d streaming, ring KV cache full (%d frames), Mimi encode + LM decode HIP path"
                                    % (args.config, B, fill),
                        "streams_per_gpu": B, "parallelism": "replicas x%d (independent stream batches)" % world,
-                       "streams": "single stream" if args.no_overlap else "encoder stream || model stream (as the reference's two threads)",
+                       "streams": "single stream" if args.no_overlap else "encoder stream || %d LM group stream(s)" % len(groups),
                        "weights_broadcast_ms": bcast_ms},
-            "roofline": {"bound": "hbm", "kernel": "attn_kernel<bf16,hd%d,T1> (LM ring-cache attention, %d launches/step)" % (hd, L),
+            "roofline": {"bound": "hbm", "kernel": "attn_kernel<bf16,hd%d,T1> (LM ring-cache attention, %d launches/step: %d layers x %d stream groups of %s slots)"
+                                                    % (hd, L * len(groups), L, len(groups), "/".join(str(n) for _, n in groups)),
                          "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "algorithmic_bytes_per_launch": attn_bytes, "avg_launch_us": attn_avg_us,
-                         "launches_timed": int(attn_n), "traffic": traffic,
+                         "launches_timed": int(attn_n), "timer": "device wall clock inside the kernel (agrees with rocprofv3 --kernel-trace)",
+                         "hip_event_bracket_avg_us": ev_us / max(ev_n, 1), "traffic": traffic,
                          "traffic_source": "profiles/r01/pmc_hbm_traffic.json (rocprofv3 --pmc, separate passes)" if traffic else None,
-                         "isolated_single_stream": {"avg_launch_us": iso["attn_lm"][0] / max(iso["attn_lm"][1], 1),
-                                                    "achieved": attn_bytes / (iso["attn_lm"][0] / max(iso["attn_lm"][1], 1) * 1e-6) / 1e9,
-                                                    "frac": attn_bytes / (iso["attn_lm"][0] / max(iso["attn_lm"][1], 1) * 1e-6) / 1e9 / 8000.0}},
+                         "isolated_single_stream": {"avg_launch_us": iso_avg_us,
+                                                    "achieved": attn_bytes / (iso_avg_us * 1e-6) / 1e9,
+                                                    "frac": attn_bytes / (iso_avg_us * 1e-6) / 1e9 / 8000.0}},
             "step_breakdown_us_single_stream": breakdown,
+            "whole_step": {"algorithmic_bytes": step_bytes, "achieved": step_bytes / (ms_per_step * 1e-3) / 1e9, "unit": "GB/s",
+                           "frac_of_hbm_peak": step_bytes / (ms_per_step * 1e-3) / 1e9 / 8000.0},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, B, lm_path, mimi_path, args.cpu_steps)

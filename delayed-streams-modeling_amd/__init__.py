@@ -86,6 +86,7 @@ ABI_SYMBOLS = [
     "dsm_get_metrics", "dsm_batch_size", "dsm_n_q", "dsm_mimi_encode_step_dev", "dsm_asr_step_tokens_dev",
     "dsm_streams_join", "dsm_debug_read", "dsm_asr_step_pcm_dev", "dsm_prof_enable", "dsm_prof_read",
     "dsm_debug_set_positions", "dsm_mimi_decode_step", "dsm_mimi_decode_step_dev",
+    "dsm_lm_stream_groups", "dsm_debug_serialize_groups", "dsm_prof_read_device",
     "dsm_tts_config_v202501", "dsm_tts_create", "dsm_tts_destroy", "dsm_tts_last_error", "dsm_tts_step",
     "dsm_tts_audio_tokens", "dsm_tts_step_idx", "dsm_tts_reset_slot", "dsm_tts_debug_read",
 ]
@@ -143,6 +144,12 @@ def load_library(path=None):
                  "dsm_n_q", "dsm_mimi_encode_step_dev", "dsm_asr_step_tokens_dev", "dsm_streams_join",
                  "dsm_debug_read", "dsm_asr_step_pcm_dev", "dsm_prof_enable", "dsm_prof_read"):
         getattr(lib, name).restype = C.c_int
+    lib.dsm_prof_read_device.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    lib.dsm_prof_read_device.restype = C.c_int
+    lib.dsm_lm_stream_groups.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
+    lib.dsm_lm_stream_groups.restype = C.c_int
+    lib.dsm_debug_serialize_groups.argtypes = [vp, C.c_int]
+    lib.dsm_debug_serialize_groups.restype = C.c_int
     lib.dsm_tts_config_v202501.argtypes = [C.POINTER(TtsConfig)]
     lib.dsm_tts_config_v202501.restype = None
     lib.dsm_tts_create.argtypes = [C.POINTER(TtsConfig), C.c_int, C.c_int, C.c_char_p, C.POINTER(vp)]
@@ -366,6 +373,22 @@ class AsrEngine:
 
     def debug_set_positions(self, lm_pos, mimi_pos):
         self._check(self.lib.dsm_debug_set_positions(self.h, lm_pos, mimi_pos))
+
+    def prof_read_device(self):
+        """Like prof_read, from the in-kernel device-clock brackets (attention classes only)."""
+        tot = (C.c_double * len(PROF_TAGS))()
+        cnt = (C.c_uint64 * len(PROF_TAGS))()
+        self._check(self.lib.dsm_prof_read_device(self.h, tot, cnt))
+        return {t: (tot[i], cnt[i]) for i, t in enumerate(PROF_TAGS)}
+
+    def stream_groups(self):
+        """[(first_slot, n_slots), ...] of the LM stream groups."""
+        a, b = (C.c_int * 8)(), (C.c_int * 8)()
+        g = self._check(self.lib.dsm_lm_stream_groups(self.h, a, b, 8))
+        return [(a[i], b[i]) for i in range(g)]
+
+    def debug_serialize_groups(self, on):
+        self._check(self.lib.dsm_debug_serialize_groups(self.h, 1 if on else 0))
 
     def prof_enable(self, tags):
         mask = 0

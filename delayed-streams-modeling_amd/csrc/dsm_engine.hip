@@ -156,7 +156,15 @@ struct LmState {
         *eh = nullptr, *prs = nullptr;
   uint32_t *next_cb = nullptr, *text_token = nullptr, *text_out = nullptr, *codes_in = nullptr;
   uint8_t *first_step = nullptr, *mask = nullptr;
+  uint8_t* gmask = nullptr;  // per-group private copy of the step's mask (groups free-run against each other)
   TransformerState tr;
+  // stream groups: slots [b0, b0+nb) of group g step on their own HIP stream so that one group's HBM-bound attention
+  // overlaps another's MFMA-bound GEMMs; rows are independent, so the split changes no result
+  struct Group {
+    int b0 = 0, nb = 0;
+    TransformerState view;  // tr with every per-slot pointer advanced to b0
+  };
+  std::vector<Group> groups;
 };
 
 struct HostItem {  // ItemState — core/asr.rs:15-51 (word assembly stays on the host)
@@ -172,6 +180,11 @@ struct dsm_engine {
   dsm_asr_config cfg{};
   int B = 0, device = 0;
   hipStream_t s_enc = nullptr, s_model = nullptr;
+  static constexpr int kMaxGroups = 4;
+  hipStream_t s_grp[kMaxGroups] = {nullptr, nullptr, nullptr, nullptr};  // s_grp[0] is unused (group 0 runs on s_model)
+  hipEvent_t ev_fork = nullptr, ev_grp_in[kMaxGroups] = {}, ev_grp_done[kMaxGroups] = {};
+  bool grp_busy = false;
+  bool serialize_groups = false;  // dsm_debug_serialize_groups: every group on the model stream (profiling aid)
   hipEvent_t ev_codes_consumed = nullptr;
   bool codes_consumed_valid = false;
   hipEvent_t ev_join = nullptr, ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;
@@ -196,14 +209,21 @@ struct dsm_engine {
   std::vector<uint32_t> msg_tokens;
   dsm_metrics metrics{};
   // split-K workspaces of the tiled GEMM, one per stream (0 = encoder, 1 = model); grown on first use
-  float* gemm_ws[2] = {nullptr, nullptr};
-  size_t gemm_ws_cap[2] = {0, 0};
+  static constexpr int kStreams = 1 + kMaxGroups;
+  float* gemm_ws[kStreams] = {};
+  size_t gemm_ws_cap[kStreams] = {};
   // per-kernel-class event timing (dsm_prof_*)
   unsigned prof_mask = 0;
   // one slot per stream (0 = encoder, 1 = model): the two host threads of the worker never share a slot
-  int tag_gemm[2] = {DSM_PROF_OTHER, DSM_PROF_OTHER}, tag_attn[2] = {DSM_PROF_OTHER, DSM_PROF_OTHER};
+  int tag_gemm[kStreams] = {DSM_PROF_OTHER, DSM_PROF_OTHER, DSM_PROF_OTHER, DSM_PROF_OTHER, DSM_PROF_OTHER};
+  int tag_attn[kStreams] = {DSM_PROF_OTHER, DSM_PROF_OTHER, DSM_PROF_OTHER, DSM_PROF_OTHER, DSM_PROF_OTHER};
   std::mutex prof_mu, err_mu;
-  int sid(hipStream_t st) const { return st == s_enc ? 0 : 1; }
+  int sid(hipStream_t st) const {  // 0 = encoder, 1 = model (= group 0), 1 + g = group g
+    if (st == s_enc) return 0;
+    for (int g = 1; g < kMaxGroups; ++g)
+      if (st == s_grp[g]) return 1 + g;
+    return 1;
+  }
   struct ProfRec {
     int tag;
     hipEvent_t a, b;
@@ -212,6 +232,18 @@ struct dsm_engine {
   std::vector<hipEvent_t> prof_pool;
   double prof_total_us[DSM_PROF_NTAGS] = {0};
   uint64_t prof_launches[DSM_PROF_NTAGS] = {0};
+
+  // in-kernel launch brackets (attention kernels): device buffer of (min start, max end) wall-clock pairs
+  static constexpr size_t kDevTsCap = 1 << 16;
+  unsigned long long* dev_ts = nullptr;
+  std::vector<int> dev_ts_tags;  // tag of record i (records are handed out in launch order)
+  unsigned long long* dev_ts_slot(int tag) {
+    if (!dev_ts || !(prof_mask & (1u << tag))) return nullptr;
+    std::lock_guard<std::mutex> lk(prof_mu);
+    if (dev_ts_tags.size() >= kDevTsCap) return nullptr;
+    dev_ts_tags.push_back(tag);
+    return dev_ts + 2 * (dev_ts_tags.size() - 1);
+  }
 
   hipEvent_t prof_event() {
     if (!prof_pool.empty()) {
@@ -701,7 +733,7 @@ int launch_gemm_tiled(dsm_engine* e, hipStream_t st, GemmArgs& a) {
   a.ws_ntiles = (((NT - 1) * a.nt_stride) >> 4) + gx * 4;
   const int mtiles = (a.M + 15) / 16;
   if (chunks > 1) {
-    const int wsid = (st == e->s_enc) ? 0 : 1;
+    const int wsid = e->sid(st);
     size_t need = (size_t)chunks * mtiles * a.ws_ntiles * 256 * sizeof(float);
     if (need > e->gemm_ws_cap[wsid]) {  // first use of a bigger shape: grow (never happens in steady state)
       HIPCHK(hipStreamSynchronize(st));

@@ -92,6 +92,32 @@ __device__ __forceinline__ void load_w8<float>(const float* p, float (&o)[8]) {
   o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
 }
 
+// 8 consecutive cache elements kept as raw words until they are used (prefetch registers of the attention kernel)
+template <typename KVT>
+struct Raw8;
+template <>
+struct Raw8<uint16_t> {
+  uint4 v;
+  __device__ __forceinline__ void load(const uint16_t* p) { v = *reinterpret_cast<const uint4*>(p); }
+  __device__ __forceinline__ void unpack(float (&o)[8]) const {
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xFFFF0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xFFFF0000u);
+    o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xFFFF0000u);
+    o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xFFFF0000u);
+  }
+};
+template <>
+struct Raw8<float> {
+  float4 a, b;
+  __device__ __forceinline__ void load(const float* p) {
+    a = *reinterpret_cast<const float4*>(p);
+    b = *reinterpret_cast<const float4*>(p + 4);
+  }
+  __device__ __forceinline__ void unpack(float (&o)[8]) const {
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+  }
+};
+
 __device__ __forceinline__ void store_kv(uint16_t* p, float v) { *p = dsm_f32_to_bf16(v); }
 __device__ __forceinline__ void store_kv(float* p, float v) { *p = v; }
 
@@ -346,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs a) {
   constexpr int PIECES = 16 * MT * 8;
   constexpr bool TWO = PIECES > 256;
   const bool has0 = tid < PIECES;
-  const int row0 = has0 ? (tid >> 3) : 0, part = tid & 7;
+  const int row0 = has0 ? (tid >> 3) : 0, part = tid & 7;  // !has0: loads row 0 (valid), stores nothing
   int m0 = m_base + row0;
   m0 = m0 < a.M ? m0 : a.M - 1;
   const float* xsrc0 = a.X + a.xmap.off(m0) + 4 * part;
@@ -362,49 +388,52 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs a) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // operand fetch runs TWO K-blocks ahead of the MFMAs (register sets A and B alternate): L2/HBM latency under
-  // load exceeds one block's worth of MFMAs (32 x 32 cycles)
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 xa0 = z4, xa1 = z4, xb0 = z4, xb1 = z4;
-  float wA[NT][8], wB[NT][8];
-#define DSM_FETCH(X0, X1, WR, KB)                                                       \
-  {                                                                                     \
-    if (has0) X0 = *reinterpret_cast<const float4*>(xsrc0 + (KB));                      \
-    if (TWO) X1 = *reinterpret_cast<const float4*>(xsrc1 + (KB));                       \
-    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) load_w8<WT>(wrow[nt] + (KB), WR[nt]); \
+  // Every load of the chunk — 8 activation pieces and 8 weight fragments per thread — is requested up front, in the
+  // order the blocks consume them and without a branch around any of them (block indices are clamped to the chunk's
+  // last block; threads without an activation piece load a row they never store).  A load under a branch makes the
+  // compiler wait for it on the spot, and s_waitcnt counts loads in issue order, so fetching "two blocks ahead"
+  // inside the loop had been serialising every block behind the HBM latency: half the MFMA rate.  Now the latency
+  // is paid once per workgroup, while the co-resident workgroups (3-4 per CU) keep the MFMA pipe busy.
+  const int nkb = (k1 - k0) >> 5;  // 1..8 blocks of 32
+  // named scalars, not arrays: the 8-entry prefetch arrays were left in scratch memory by the compiler
+#define DSM_FOR8(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7)
+#define DSM_LOADBLK(I)                                                                 \
+  float4 xp##I, xq##I;                                                                 \
+  Raw8<WT> rw##I[NT];                                                                  \
+  {                                                                                    \
+    const int kb_ = k0 + 32 * ((I) < nkb ? (I) : nkb - 1);                             \
+    xp##I = *reinterpret_cast<const float4*>(xsrc0 + kb_);                             \
+    xq##I = TWO ? *reinterpret_cast<const float4*>(xsrc1 + kb_) : xp##I;               \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) rw##I[nt].load(wrow[nt] + kb_);  \
   }
-#define DSM_STEP(X0, X1, WR, KB)                                                        \
-  {                                                                                     \
-    float* xs = &Xs[buf][0][0];                                                         \
-    if (has0) *reinterpret_cast<float4*>(xs + xdst0) = X0;                              \
-    if (TWO) *reinterpret_cast<float4*>(xs + xdst1) = X1;                               \
-    float wa[NT][8];                                                                    \
-    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                   \
-    _Pragma("unroll") for (int j = 0; j < 8; ++j) wa[nt][j] = WR[nt][j];                \
-    __syncthreads();                                                                    \
-    if ((KB) + 64 < k1) DSM_FETCH(X0, X1, WR, (KB) + 64)                                \
-    float xb[MT][8];                                                                    \
-    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                 \
-      const float* fp = xs + (16 * mt + r) * DSM_XS_LD + 8 * q;                         \
+  DSM_FOR8(DSM_LOADBLK)
+  __builtin_amdgcn_sched_barrier(0);  // all requests issued before the first block waits for its own
+#define DSM_BLOCK(I)                                                                   \
+  if ((I) < nkb) { /* workgroup-uniform */                                             \
+    float* xs = &Xs[(I) & 1][0][0];                                                    \
+    if (has0) *reinterpret_cast<float4*>(xs + xdst0) = xp##I;                          \
+    if (TWO) *reinterpret_cast<float4*>(xs + xdst1) = xq##I;                           \
+    __syncthreads();                                                                   \
+    float wa[NT][8];                                                                   \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) rw##I[nt].unpack(wa[nt]);        \
+    float xb[MT][8];                                                                   \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                \
+      const float* fp = xs + (16 * mt + r) * DSM_XS_LD + 8 * q;                        \
       float4 f0 = *reinterpret_cast<const float4*>(fp), f1 = *reinterpret_cast<const float4*>(fp + 4); \
-      xb[mt][0] = f0.x; xb[mt][1] = f0.y; xb[mt][2] = f0.z; xb[mt][3] = f0.w;           \
-      xb[mt][4] = f1.x; xb[mt][5] = f1.y; xb[mt][6] = f1.z; xb[mt][7] = f1.w;           \
-    }                                                                                   \
-    _Pragma("unroll") for (int s = 0; s < 8; ++s)                                       \
-    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                   \
-    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                   \
-        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nt][s], xb[mt][s], acc[nt][mt], 0, 0, 0); \
-    buf ^= 1;                                                                           \
+      xb[mt][0] = f0.x; xb[mt][1] = f0.y; xb[mt][2] = f0.z; xb[mt][3] = f0.w;          \
+      xb[mt][4] = f1.x; xb[mt][5] = f1.y; xb[mt][6] = f1.z; xb[mt][7] = f1.w;          \
+    }                                                                                  \
+    _Pragma("unroll") for (int s = 0; s < 8; ++s) {                                    \
+      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                \
+      _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                \
+          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nt][s], xb[mt][s], acc[nt][mt], 0, 0, 0); \
+      if (NT * MT > 1) __builtin_amdgcn_sched_barrier(0); /* round-robin over the accumulators */ \
+    }                                                                                  \
   }
-  int buf = 0;
-  DSM_FETCH(xa0, xa1, wA, k0)
-  if (k0 + 32 < k1) DSM_FETCH(xb0, xb1, wB, k0 + 32)
-  for (int kb = k0; kb < k1; kb += 64) {
-    DSM_STEP(xa0, xa1, wA, kb)
-    if (kb + 32 < k1) DSM_STEP(xb0, xb1, wB, kb + 32)
-  }
-#undef DSM_FETCH
-#undef DSM_STEP
+  DSM_FOR8(DSM_BLOCK)
+#undef DSM_FOR8
+#undef DSM_LOADBLK
+#undef DSM_BLOCK
 
   if (chunks > 1) {
     // slab[chunk][m][n] f32, row-major with ld = ws_ntiles*16: a lane stores its 4 consecutive n of row m
@@ -605,14 +634,21 @@ __global__ __launch_bounds__(256) void row_norm_kernel(float* __restrict__ y, co
 // wave-instruction, key j -> wave (j/G)%4, lane group j%G (canonical order, dsm_numerics.h).
 // ------------------------------------------------------------------------------------------
 template <typename KVT, int HD, int T>
-__global__ __launch_bounds__(256) void attn_kernel(float* __restrict__ out, const float* __restrict__ qbuf,
+__global__ __launch_bounds__(256, 4) void attn_kernel(float* __restrict__ out, const float* __restrict__ qbuf,
                                                    const KVT* __restrict__ kcache, const KVT* __restrict__ vcache,
                                                    const uint32_t* __restrict__ start_pos,
-                                                   const uint8_t* __restrict__ active, int H, int ctx, int d) {
+                                                   const uint8_t* __restrict__ active, int H, int ctx, int d,
+                                                   unsigned long long* __restrict__ ts) {
   constexpr int NW = 4, LPK = HD / 8, G = 64 / LPK;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int b = blockIdx.x / H, h = blockIdx.x % H;
-  if (!active[b]) return;  // inactive slots: output unused by the reference (core/asr.rs:221-223)
+  // optional device-clock bracket of the whole launch (dsm_prof_read_device): first workgroup in, last one out.
+  // HIP events around a launch also count the time it queues behind other streams' kernels; this does not.
+  if (ts && threadIdx.x == 0) atomicMin(&ts[0], wall_clock64());
+  if (!active[b]) {  // inactive slots: output unused by the reference (core/asr.rs:221-223)
+    if (ts && threadIdx.x == 0) atomicMax(&ts[1], wall_clock64());
+    return;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane / LPK, li = lane % LPK;
   float* sc = lds;                       // [T][ctx]
@@ -635,34 +671,49 @@ __global__ __launch_bounds__(256) void attn_kernel(float* __restrict__ out, cons
   const KVT* Kb = kcache + ((long)b * H + h) * ctx * HD;
   const KVT* Vb = vcache + ((long)b * H + h) * ctx * HD;
 
-  // ---- phase 1: scores.  UNR independent 16-byte K loads in flight per lane; out-of-range keys are
-  // clamped to the last valid row (loaded, never used) so that the loads need no branches ----
-  constexpr int UNR = 4;
+  // ---- phase 1: scores.  Software-pipelined: while one batch of UNR keys per lane is reduced, the next batch's
+  // 16-byte loads are already in flight (raw cache words, converted at use), so a wave keeps UNR..2*UNR loads
+  // outstanding instead of draining to zero every iteration.  Out-of-range keys are clamped to the last valid row
+  // (loaded, never used) so that the loads need no branches. ----
+  constexpr int UNR = sizeof(KVT) == 2 ? 8 : 4;
+  constexpr int STEP = UNR * NW * G;
   const int jlast = nvalid - 1;
   const int last_slot = (int)(e1 % ctx);  // ring slot holding the newest key
-  for (int j0 = wave * G; j0 < nvalid; j0 += UNR * NW * G) {
-    float kv[UNR][8];
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      const int j = min(j0 + u * NW * G + g, jlast);
-      load_w8<KVT>(Kb + (long)j * HD + 8 * li, kv[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      const int j = j0 + u * NW * G + g;
-      int delta = last_slot - min(j, jlast);  // == (e1 - j) mod ctx without a 64-bit division
-      delta += (delta < 0) ? ctx : 0;
-#pragma unroll
-      for (int t = 0; t < T; ++t) {
-        float p = 0.0f;
-#pragma unroll
-        for (int dd = 0; dd < 8; ++dd) p = DSM_FMAF(qv[t][dd], kv[u][dd], p);
-#pragma unroll
-        for (int off = LPK / 2; off >= 1; off >>= 1) p = p + __shfl_xor(p, off, 64);
-        if (li == 0 && j < nvalid) sc[t * ctx + j] = (delta >= T - 1 - t) ? p * scale : -DSM_INF_F;
-      }
+  Raw8<KVT> ra[UNR], rb[UNR];
+#define DSM_ISSUE(R, BASE, J0)                                                        \
+  _Pragma("unroll") for (int u = 0; u < UNR; ++u) {                                    \
+    const int jj = min((J0) + u * NW * G + g, jlast);                                  \
+    R[u].load(BASE + (long)jj * HD + 8 * li);                                          \
+  }
+#define DSM_SCORES(R, J0)                                                              \
+  _Pragma("unroll") for (int u = 0; u < UNR; ++u) {                                    \
+    const int j = (J0) + u * NW * G + g;                                               \
+    int delta = last_slot - min(j, jlast); /* == (e1 - j) mod ctx, no 64-bit division */ \
+    delta += (delta < 0) ? ctx : 0;                                                    \
+    float kv[8];                                                                       \
+    R[u].unpack(kv);                                                                   \
+    _Pragma("unroll") for (int t = 0; t < T; ++t) {                                    \
+      float p = 0.0f;                                                                  \
+      _Pragma("unroll") for (int dd = 0; dd < 8; ++dd) p = DSM_FMAF(qv[t][dd], kv[dd], p); \
+      _Pragma("unroll") for (int off = LPK / 2; off >= 1; off >>= 1) p = p + __shfl_xor(p, off, 64); \
+      if (li == 0 && j < nvalid) sc[t * ctx + j] = (delta >= T - 1 - t) ? p * scale : -DSM_INF_F; \
+    }                                                                                  \
+  }
+  {
+    int j0 = wave * G;
+    DSM_ISSUE(ra, Kb, j0)
+    while (j0 < nvalid) {
+      DSM_ISSUE(rb, Kb, j0 + STEP)
+      DSM_SCORES(ra, j0)
+      j0 += STEP;
+      if (j0 >= nvalid) break;
+      DSM_ISSUE(ra, Kb, j0 + STEP)
+      DSM_SCORES(rb, j0)
+      j0 += STEP;
     }
   }
+  // the first batch of V rows does not depend on the softmax: put it in flight across the statistics phase
+  DSM_ISSUE(ra, Vb, wave * G)
   __syncthreads();
 
   // ---- phase 1.5: softmax statistics (softmax_last_dim) ----
@@ -696,25 +747,32 @@ __global__ __launch_bounds__(256) void attn_kernel(float* __restrict__ out, cons
   for (int t = 0; t < T; ++t)
 #pragma unroll
     for (int dd = 0; dd < 8; ++dd) acc[t][dd] = 0.0f;
-  for (int j0 = wave * G; j0 < nvalid; j0 += UNR * NW * G) {
-    float vv[UNR][8];
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      const int j = min(j0 + u * NW * G + g, jlast);
-      load_w8<KVT>(Vb + (long)j * HD + 8 * li, vv[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {  // ascending j per (wave, group): the canonical accumulation order
-      const int j = j0 + u * NW * G + g;
-#pragma unroll
-      for (int t = 0; t < T; ++t) {
-        // out-of-range keys get weight 0: fmaf(0, v, acc) == acc for the finite v of the clamped row
-        const float wgt = (j < nvalid) ? sc[t * ctx + j] / lsum[t] : 0.0f;
-#pragma unroll
-        for (int dd = 0; dd < 8; ++dd) acc[t][dd] = DSM_FMAF(wgt, vv[u][dd], acc[t][dd]);
-      }
+#define DSM_PV(R, J0)                                                                  \
+  _Pragma("unroll") for (int u = 0; u < UNR; ++u) { /* ascending j per (wave, group): canonical order */ \
+    const int j = (J0) + u * NW * G + g;                                               \
+    float vv[8];                                                                       \
+    R[u].unpack(vv);                                                                   \
+    _Pragma("unroll") for (int t = 0; t < T; ++t) {                                    \
+      /* out-of-range keys get weight 0: fmaf(0, v, acc) == acc for the finite v of the clamped row */ \
+      const float wgt = (j < nvalid) ? sc[t * ctx + j] / lsum[t] : 0.0f;               \
+      _Pragma("unroll") for (int dd = 0; dd < 8; ++dd) acc[t][dd] = DSM_FMAF(wgt, vv[dd], acc[t][dd]); \
+    }                                                                                  \
+  }
+  {
+    int j0 = wave * G;  // ra already holds this batch
+    while (j0 < nvalid) {
+      DSM_ISSUE(rb, Vb, j0 + STEP)
+      DSM_PV(ra, j0)
+      j0 += STEP;
+      if (j0 >= nvalid) break;
+      DSM_ISSUE(ra, Vb, j0 + STEP)
+      DSM_PV(rb, j0)
+      j0 += STEP;
     }
   }
+#undef DSM_ISSUE
+#undef DSM_SCORES
+#undef DSM_PV
 #pragma unroll
   for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -737,6 +795,7 @@ __global__ __launch_bounds__(256) void attn_kernel(float* __restrict__ out, cons
                 red[(3 * T + t) * HD + dd];
     out[((long)(b * T + t)) * d + h * HD + dd] = tot;
   }
+  if (ts && threadIdx.x == 0) atomicMax(&ts[1], wall_clock64());
 }
 
 // ------------------------------------------------------------------------------------------
@@ -931,7 +990,7 @@ __global__ void dep_argmax_kernel(const float* __restrict__ logits, int V, int k
 
 // extra heads: f32 softmax over `dim` classes, class-0 probability -> prs[head][slot] (core/asr.rs:195-203)
 __global__ void extra_heads_kernel(const float* __restrict__ eh /* [B][nh*dim] */, float* __restrict__ prs, int B,
-                                   int nh, int dim) {
+                                   int nh, int dim, int prs_stride /* slots of the whole batch */) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * nh) return;
   int b = i / nh, h = i % nh;
@@ -944,7 +1003,7 @@ __global__ void extra_heads_kernel(const float* __restrict__ eh /* [B][nh*dim] *
     if (k == 0) e0 = e;
     sum = sum + e;
   }
-  prs[(long)h * B + b] = e0 / sum;
+  prs[(long)h * prs_stride + b] = e0 / sum;
 }
 
 // ------------------------------------------------------------------------------------------

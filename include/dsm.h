@@ -213,6 +213,10 @@ enum { DSM_PROF_ATTN_LM = 0, DSM_PROF_GEMM_LM = 1, DSM_PROF_ATTN_MIMI = 2, DSM_P
        DSM_PROF_RVQ = 4, DSM_PROF_OTHER = 5, DSM_PROF_NTAGS = 6 };
 int dsm_prof_enable(dsm_engine*, unsigned tag_mask);
 int dsm_prof_read(dsm_engine*, double* total_us /*[DSM_PROF_NTAGS]*/, uint64_t* launches /*[DSM_PROF_NTAGS]*/);
+/* Same classes, but bracketed INSIDE the kernel with the device wall clock (first workgroup in, last workgroup out):
+ * the duration rocprofv3's kernel trace reports.  With several streams in flight a HIP-event bracket also counts the
+ * time a launch queues behind other streams' kernels.  Instrumented classes: ATTN_LM, ATTN_MIMI (others read 0). */
+int dsm_prof_read_device(dsm_engine*, double* total_us /*[DSM_PROF_NTAGS]*/, uint64_t* launches /*[DSM_PROF_NTAGS]*/);
 
 /* ------------------------------------------------------------------------------------------------
  * TTS (BASELINE.json configs[4]): tts_streaming::State::step + LmModel::forward_cond + DepFormer::sample
@@ -252,6 +256,13 @@ int dsm_tts_audio_tokens(dsm_tts*, int slot, int step, uint32_t* out /* [num_sli
 int dsm_tts_step_idx(dsm_tts*, int slot);
 int dsm_tts_reset_slot(dsm_tts*, int slot);
 int dsm_tts_debug_read(dsm_tts*, const char* name, float* out, size_t cap); /* "lm.hidden", "lm.logits" */
+
+/* The LM step splits the batch into stream groups (slots [first, first+n) each on its own HIP stream) so that one
+ * group's HBM-bound attention overlaps another's MFMA-bound GEMMs; results do not depend on the split.  Returns the
+ * number of groups and fills up to `cap` entries.  Environment DSM_LM_GROUPS (1..4) overrides the default at create. */
+int dsm_lm_stream_groups(dsm_engine*, int* first_slot, int* n_slots, int cap);
+/* Profiling aid: run every group on the model stream, one after the other (per-kernel timings without overlap). */
+int dsm_debug_serialize_groups(dsm_engine*, int on);
 
 /* Profiling aid: pretend every slot already streamed `pos` frames (ring index = pos mod ctx, cache content
  * untouched) so that short profiler runs see steady-state attention traffic.  Never used for `value`. */

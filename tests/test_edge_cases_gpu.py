@@ -85,3 +85,46 @@ def test_create_destroy_cycles(gpu, dsm, lib, tiny_weights):
         eng.decode_step(np.zeros((8, cfg.mimi.quantizer_n_q), dtype=np.uint32), np.ones(8, dtype=np.uint8))
         eng.close()
     assert free0 - torch.cuda.mem_get_info()[0] < 64 << 20, "device memory leaked across create/destroy"
+
+
+@pytest.mark.parametrize("groups", ["3", "1"])
+def test_stream_groups_do_not_change_results(gpu, dsm, lib, orc, tiny_weights, monkeypatch, groups):
+    """The LM step splits the batch into stream groups that free-run on their own HIP streams (slots 0-15, 16-31,
+    32-39 here).  Rows are independent, so tokens, VAD heads and words must equal the oracle's for any grouping,
+    through masks, resets and the device-pointer entry points that never join the groups."""
+    import torch
+    from dsm_amd import synth
+    monkeypatch.setenv("DSM_LM_GROUPS", groups)
+    cfg = dsm.config_tiny()
+    B, steps = 40, 16
+    eng = dsm.AsrEngine(cfg, B, *tiny_weights)
+    ora = orc.OracleAsr(cfg, B, *tiny_weights)
+    pcm = synth.synth_pcm(B, steps)
+    rng = np.random.default_rng(4)
+    masks = (rng.random((steps, B)) < 0.8).astype(np.uint8)
+    nh = cfg.extra_heads_num
+    dev = torch.device("cuda", 0)
+    d_text = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_prs = torch.zeros(nh * B, dtype=torch.float32, device=dev)
+    d_codes = torch.zeros(B * cfg.audio_codebooks, dtype=torch.int32, device=dev)
+    for s in range(steps):
+        if s == 7:
+            for slot in (3, 20, 39):
+                eng.reset_batch_idx(slot); ora.reset_batch_idx(slot)
+        act = masks[s].astype(bool)
+        oc, ot, op = ora.step_pcm(pcm[s], masks[s])
+        if s % 2 == 0:  # host-pointer entry
+            ec, et, ep = eng.step_pcm(pcm[s], masks[s])
+        else:  # device-pointer entry: nothing synchronised, groups keep running into the next call
+            d_pcm = torch.from_numpy(pcm[s]).to(dev)
+            d_mask = torch.from_numpy(masks[s]).to(dev)
+            eng.step_pcm_dev(d_pcm.data_ptr(), d_mask.data_ptr(), d_codes.data_ptr(), d_text.data_ptr(), d_prs.data_ptr())
+            eng.sync()
+            ec = d_codes.cpu().numpy().astype(np.uint32).reshape(B, -1)
+            et = d_text.cpu().numpy().astype(np.uint32)
+            ep = d_prs.cpu().numpy().reshape(nh, B)
+        assert np.array_equal(ec[act], oc[act]), f"codes differ at step {s}"
+        assert np.array_equal(et[act], ot[act]), f"text tokens differ at step {s}"
+        assert np.array_equal(ep[:, act].view(np.uint32), op[:, act].view(np.uint32)), f"VAD heads differ at step {s}"
+    eng.close()
+    ora.close()

@@ -12,4 +12,5 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpu
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 400 rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/prof/pmc_$c -- python3 bench.py --fast-fill --no-overlap --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/prof/pmc_$c.json 2> gpurun_out/prof/pmc_$c.err; echo "pmc $c rc=$?"
 done
+python3 tools/pmc_summary.py gpurun_out/prof/pmc_FETCH_SIZE gpurun_out/prof/pmc_WRITE_SIZE 16 > gpurun_out/prof/pmc_hbm_traffic.json
 python3 tools/trace_summary.py gpurun_out/prof/trace 12
