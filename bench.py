@@ -201,6 +201,8 @@ def main():
 
     if args.workload == "mimi-decode":
         return bench_decode(args, eng, cfg, B, dev, world, rank, dist, torch)
+    if args.no_overlap:
+        eng.debug_serialize_groups(True)  # one stream for everything: kernels run alone (profiling runs)
     ctx = cfg.lm.context
     n_pcm = 16
     pcm = torch.from_numpy(synth.synth_pcm(B, n_pcm, seed=1000 + 7919 * rank)).to(dev)  # [n_pcm, B, 1920]
@@ -270,7 +272,7 @@ def main():
     iso_dev = eng.prof_read_device()
     breakdown = {k: round(v[0] / 5.0, 1) for k, v in iso.items()}
     eng.prof_enable([])
-    eng.debug_serialize_groups(False)
+    eng.debug_serialize_groups(not overlap)
     args.no_overlap = not overlap
     groups = eng.stream_groups()
 
