@@ -87,6 +87,8 @@ ABI_SYMBOLS = [
     "dsm_streams_join", "dsm_debug_read", "dsm_asr_step_pcm_dev", "dsm_prof_enable", "dsm_prof_read",
     "dsm_debug_set_positions", "dsm_mimi_decode_step", "dsm_mimi_decode_step_dev",
     "dsm_lm_stream_groups", "dsm_debug_serialize_groups", "dsm_prof_read_device",
+    "dsm_wav_decode", "dsm_free", "dsm_linear_resampler_new", "dsm_linear_resampler_process",
+    "dsm_linear_resampler_free",
     "dsm_tts_config_v202501", "dsm_tts_create", "dsm_tts_destroy", "dsm_tts_last_error", "dsm_tts_step",
     "dsm_tts_audio_tokens", "dsm_tts_step_idx", "dsm_tts_reset_slot", "dsm_tts_debug_read",
 ]
@@ -150,6 +152,17 @@ def load_library(path=None):
     lib.dsm_lm_stream_groups.restype = C.c_int
     lib.dsm_debug_serialize_groups.argtypes = [vp, C.c_int]
     lib.dsm_debug_serialize_groups.restype = C.c_int
+    lib.dsm_wav_decode.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_size_t),
+                                   C.POINTER(C.c_int)]
+    lib.dsm_wav_decode.restype = C.c_int
+    lib.dsm_free.argtypes = [vp]
+    lib.dsm_free.restype = None
+    lib.dsm_linear_resampler_new.argtypes = [C.c_uint32, C.c_uint32]
+    lib.dsm_linear_resampler_new.restype = vp
+    lib.dsm_linear_resampler_process.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t]
+    lib.dsm_linear_resampler_process.restype = C.c_size_t
+    lib.dsm_linear_resampler_free.argtypes = [vp]
+    lib.dsm_linear_resampler_free.restype = None
     lib.dsm_tts_config_v202501.argtypes = [C.POINTER(TtsConfig)]
     lib.dsm_tts_config_v202501.restype = None
     lib.dsm_tts_create.argtypes = [C.POINTER(TtsConfig), C.c_int, C.c_int, C.c_char_p, C.POINTER(vp)]
@@ -247,6 +260,43 @@ def _ptr(a):
 
 class DsmError(RuntimeError):
     pass
+
+
+def wav_decode(data):
+    """(pcm f32 of channel 0, sample_rate) of a RIFF/WAVE body — srv/utils.rs:263-305 pcm_decode."""
+    lib = load_library()
+    ptr, n, rate = C.POINTER(C.c_float)(), C.c_size_t(0), C.c_int(0)
+    rc = lib.dsm_wav_decode(data, len(data), C.byref(ptr), C.byref(n), C.byref(rate))
+    if rc != 0:
+        msg = lib.dsm_last_error(None)
+        raise DsmError(f"dsm_wav_decode failed ({rc}): {msg.decode() if msg else '?'}")
+    try:
+        return np.ctypeslib.as_array(ptr, shape=(n.value,)).copy() if n.value else np.zeros(0, np.float32), rate.value
+    finally:
+        lib.dsm_free(ptr)
+
+
+class LinearResampler:
+    """kyutai-client-core `LinearResampler` (audio.rs:133-183) behind the C ABI; process() is streaming."""
+
+    def __init__(self, in_rate_hz, out_rate_hz):
+        self.lib = load_library()
+        self.h = self.lib.dsm_linear_resampler_new(in_rate_hz, out_rate_hz)
+        if not self.h:
+            raise DsmError("bad sample rates")
+        self.ratio = out_rate_hz / in_rate_hz
+
+    def process(self, pcm):
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        out = np.zeros(int(pcm.size * self.ratio) + 4, dtype=np.float32)
+        n = self.lib.dsm_linear_resampler_process(self.h, _ptr(pcm), pcm.size, _ptr(out), out.size)
+        assert n <= out.size
+        return out[:n]
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.dsm_linear_resampler_free(self.h)
+            self.h = None
 
 
 class AsrEngine:

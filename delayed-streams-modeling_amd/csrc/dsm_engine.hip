@@ -877,3 +877,4 @@ int run_conv(dsm_engine* e, hipStream_t st, const ConvGeom& c, const float* cat,
 
 #include "dsm_engine_api.inc"
 #include "dsm_tts.inc"
+#include "dsm_audio.inc"

@@ -273,6 +273,20 @@ int dsm_debug_set_positions(dsm_engine*, uint32_t lm_pos, uint32_t mimi_pos);
  * Returns the number of floats written, or <0. */
 int dsm_debug_read(dsm_engine*, const char* name, float* out, size_t cap);
 
+/* ------------------------------------------------------------------------------------------------
+ * Audio ingest helpers (host only; SURVEY.md §8(f) rank 3, first part).
+ * dsm_wav_decode: channel 0 of a RIFF/WAVE body as f32 — what srv/utils.rs:263-305 `pcm_decode` hands the worker
+ * (srv/batched_asr.rs:834-842) for such a body.  *pcm_out is malloc'd; release it with dsm_free.
+ * dsm_linear_resampler_*: the clients' default resampler, client/rust/kyutai-client-core/src/audio.rs:133-183
+ * (`LinearResampler::process_into`), streaming.  mp3 / Ogg-Opus decoding is not built.
+ * ------------------------------------------------------------------------------------------------ */
+int dsm_wav_decode(const uint8_t* bytes, size_t len, float** pcm_out, size_t* n_out, int* sample_rate_out);
+void dsm_free(void*);
+typedef struct dsm_resampler dsm_resampler;
+dsm_resampler* dsm_linear_resampler_new(uint32_t in_rate_hz, uint32_t out_rate_hz);
+size_t dsm_linear_resampler_process(dsm_resampler*, const float* in, size_t n_in, float* out, size_t out_cap);
+void dsm_linear_resampler_free(dsm_resampler*);
+
 #ifdef __cplusplus
 }
 #endif
