@@ -65,9 +65,38 @@ TTS_UNGENERATED = 0xFFFFFFFF
 TTS_ALLOW_PAD, TTS_ALLOW_PAD_OR_EPAD = -1, -2
 
 
+class InMsg(C.Structure):
+    _fields_ = [("kind", C.c_int), ("id", C.c_int64), ("pcm", C.c_void_p), ("n_pcm", C.c_size_t),
+                ("data", C.c_void_p), ("n_data", C.c_size_t)]
+
+
+class OutMsg(C.Structure):
+    _fields_ = [("kind", C.c_int), ("text", C.c_char_p), ("time", C.c_double), ("id", C.c_int64),
+                ("step_idx", C.c_uint64), ("prs", C.c_void_p), ("n_prs", C.c_size_t), ("buffered_pcm", C.c_uint64)]
+
+
+IN_KINDS = ["Init", "Marker", "Audio", "OggOpus", "Ping"]
+OUT_KINDS = ["Word", "EndWord", "Marker", "Step", "Error", "Ready"]
+DETOK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.c_int, C.c_void_p, C.c_size_t)
+
+
 class AsrMsg(C.Structure):
     _fields_ = [("kind", C.c_int), ("batch_idx", C.c_int), ("step_idx", C.c_int), ("time", C.c_double),
                 ("tokens_offset", C.c_int), ("n_tokens", C.c_int), ("prs", C.c_float * MAX_EXTRA_HEADS)]
+
+
+BE_ENCODE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint8))
+BE_RESET = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
+BE_STEP = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_float))
+BE_POLL = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(AsrMsg), C.c_int, C.POINTER(C.c_uint32), C.c_int)
+BE_ERROR = C.CFUNCTYPE(C.c_char_p, C.c_void_p)
+
+
+class WorkerBackend(C.Structure):
+    """dsm_worker_backend (include/dsm.h)."""
+    _fields_ = [("self", C.c_void_p), ("batch_size", C.c_int), ("asr_delay_in_tokens", C.c_int),
+                ("extra_heads_num", C.c_int), ("encode_step", BE_ENCODE), ("reset_slot", BE_RESET),
+                ("step_tokens", BE_STEP), ("poll_msgs", BE_POLL), ("last_error", BE_ERROR)]
 
 
 class Metrics(C.Structure):
@@ -89,6 +118,9 @@ ABI_SYMBOLS = [
     "dsm_lm_stream_groups", "dsm_debug_serialize_groups", "dsm_prof_read_device",
     "dsm_wav_decode", "dsm_free", "dsm_linear_resampler_new", "dsm_linear_resampler_process",
     "dsm_linear_resampler_free",
+    "dsm_inmsg_encode", "dsm_outmsg_encode", "dsm_inmsg_decode", "dsm_outmsg_decode", "dsm_worker_create",
+    "dsm_worker_create_with_backend", "dsm_worker_destroy", "dsm_worker_last_error", "dsm_worker_set_detokenizer", "dsm_worker_open", "dsm_worker_close",
+    "dsm_worker_send", "dsm_worker_step", "dsm_worker_recv", "dsm_worker_buffered",
     "dsm_tts_config_v202501", "dsm_tts_create", "dsm_tts_destroy", "dsm_tts_last_error", "dsm_tts_step",
     "dsm_tts_audio_tokens", "dsm_tts_step_idx", "dsm_tts_reset_slot", "dsm_tts_debug_read",
 ]
@@ -163,6 +195,29 @@ def load_library(path=None):
     lib.dsm_linear_resampler_process.restype = C.c_size_t
     lib.dsm_linear_resampler_free.argtypes = [vp]
     lib.dsm_linear_resampler_free.restype = None
+    lib.dsm_inmsg_encode.argtypes = [C.POINTER(InMsg), vp, C.c_size_t]
+    lib.dsm_outmsg_encode.argtypes = [C.POINTER(OutMsg), vp, C.c_size_t]
+    lib.dsm_inmsg_decode.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(InMsg), vp, C.c_size_t, vp, C.c_size_t]
+    lib.dsm_outmsg_decode.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(OutMsg), vp, C.c_size_t, vp, C.c_size_t]
+    lib.dsm_worker_create.argtypes = [vp, C.POINTER(vp)]
+    lib.dsm_worker_create_with_backend.argtypes = [C.POINTER(WorkerBackend), C.POINTER(vp)]
+    lib.dsm_worker_create_with_backend.restype = C.c_int
+    lib.dsm_worker_destroy.argtypes = [vp]
+    lib.dsm_worker_destroy.restype = None
+    lib.dsm_worker_last_error.argtypes = [vp]
+    lib.dsm_worker_last_error.restype = C.c_char_p
+    lib.dsm_worker_set_detokenizer.argtypes = [vp, DETOK_FN, vp]
+    lib.dsm_worker_set_detokenizer.restype = None
+    lib.dsm_worker_open.argtypes = [vp, C.POINTER(C.c_uint64)]
+    lib.dsm_worker_close.argtypes = [vp, C.c_int]
+    lib.dsm_worker_send.argtypes = [vp, C.c_int, C.c_char_p, C.c_size_t]
+    lib.dsm_worker_step.argtypes = [vp]
+    lib.dsm_worker_recv.argtypes = [vp, C.c_int, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.dsm_worker_buffered.argtypes = [vp, C.c_int]
+    for name in ("dsm_inmsg_encode", "dsm_outmsg_encode", "dsm_inmsg_decode", "dsm_outmsg_decode", "dsm_worker_create",
+                 "dsm_worker_open", "dsm_worker_close", "dsm_worker_send", "dsm_worker_step", "dsm_worker_recv",
+                 "dsm_worker_buffered"):
+        getattr(lib, name).restype = C.c_int
     lib.dsm_tts_config_v202501.argtypes = [C.POINTER(TtsConfig)]
     lib.dsm_tts_config_v202501.restype = None
     lib.dsm_tts_create.argtypes = [C.POINTER(TtsConfig), C.c_int, C.c_int, C.c_char_p, C.POINTER(vp)]
@@ -260,6 +315,152 @@ def _ptr(a):
 
 class DsmError(RuntimeError):
     pass
+
+
+def encode_in_msg(kind, id=0, pcm=None, data=None):
+    """InMsg -> msgpack bytes (client/rust/kyutai-client/src/stt/protocol.rs:47-58)."""
+    lib = load_library()
+    m = InMsg()
+    m.kind, m.id = IN_KINDS.index(kind), id
+    keep = []
+    if pcm is not None:
+        a = np.ascontiguousarray(pcm, dtype=np.float32)
+        keep.append(a)
+        m.pcm, m.n_pcm = a.ctypes.data, a.size
+    if data is not None:
+        b = np.frombuffer(bytes(data), dtype=np.uint8).copy()
+        keep.append(b)
+        m.data, m.n_data = b.ctypes.data, b.size
+    n = lib.dsm_inmsg_encode(C.byref(m), None, 0)
+    buf = np.zeros(max(n, 1), dtype=np.uint8)
+    assert lib.dsm_inmsg_encode(C.byref(m), _ptr(buf), buf.size) == n
+    return buf[:n].tobytes()
+
+
+def decode_in_msg(raw):
+    """msgpack bytes -> dict, as the server's rmp_serde::from_slice::<InMsg> (srv/batched_asr.rs:927); None if rejected."""
+    lib = load_library()
+    m = InMsg()
+    pcm, data = np.zeros(len(raw) + 1, dtype=np.float32), np.zeros(len(raw) + 1, dtype=np.uint8)
+    if lib.dsm_inmsg_decode(raw, len(raw), C.byref(m), _ptr(pcm), pcm.size, _ptr(data), data.size) != 0:
+        return None
+    out = {"type": IN_KINDS[m.kind]}
+    if out["type"] == "Marker":
+        out["id"] = m.id
+    elif out["type"] == "Audio":
+        out["pcm"] = pcm[:m.n_pcm].copy()
+    elif out["type"] == "OggOpus":
+        out["data"] = data[:m.n_data].tobytes()
+    return out
+
+
+def encode_out_msg(kind, text="", time=0.0, id=0, step_idx=0, prs=(), buffered_pcm=0):
+    """OutMsg -> msgpack bytes, as send_loop serialises it (srv/batched_asr.rs:969-975)."""
+    lib = load_library()
+    m = OutMsg()
+    p = np.ascontiguousarray(prs, dtype=np.float32)
+    m.kind, m.text, m.time, m.id, m.step_idx = OUT_KINDS.index(kind), text.encode(), time, id, step_idx
+    m.prs, m.n_prs, m.buffered_pcm = p.ctypes.data, p.size, buffered_pcm
+    n = lib.dsm_outmsg_encode(C.byref(m), None, 0)
+    buf = np.zeros(max(n, 1), dtype=np.uint8)
+    assert lib.dsm_outmsg_encode(C.byref(m), _ptr(buf), buf.size) == n
+    return buf[:n].tobytes()
+
+
+def decode_out_msg(raw):
+    """msgpack bytes -> dict (client: protocol.rs:60-62 decode_out_msg); None if rejected."""
+    lib = load_library()
+    m = OutMsg()
+    text, prs = C.create_string_buffer(len(raw) + 1), np.zeros(len(raw) + 1, dtype=np.float32)
+    if lib.dsm_outmsg_decode(raw, len(raw), C.byref(m), text, len(raw) + 1, _ptr(prs), prs.size) != 0:
+        return None
+    k = OUT_KINDS[m.kind]
+    out = {"type": k}
+    if k == "Word":
+        out.update(text=text.value.decode(), start_time=m.time)
+    elif k == "EndWord":
+        out.update(stop_time=m.time)
+    elif k == "Marker":
+        out.update(id=m.id)
+    elif k == "Step":
+        out.update(step_idx=m.step_idx, prs=prs[:m.n_prs].tolist(), buffered_pcm=m.buffered_pcm)
+    elif k == "Error":
+        out.update(message=text.value.decode())
+    return out
+
+
+class Worker:
+    """moshi-server's BatchedAsr module above an AsrEngine, minus the sockets: slot table, per-channel PCM queue,
+    markers, message fan-out (srv/batched_asr.rs).  Messages cross this interface as the msgpack bytes of the wire."""
+
+    def __init__(self, engine=None, detokenizer=None, backend=None):
+        """engine: an AsrEngine (the product path).  backend: a filled WorkerBackend instead (the tests drive the
+        worker logic with the CPU oracle through it); the caller keeps its callbacks alive."""
+        self.lib, self.engine, self.backend = load_library(), engine, backend
+        h = C.c_void_p()
+        if backend is not None:
+            rc = self.lib.dsm_worker_create_with_backend(C.byref(backend), C.byref(h))
+        else:
+            rc = self.lib.dsm_worker_create(engine.h, C.byref(h))
+        if rc != 0:
+            raise DsmError("dsm_worker_create failed")
+        self.h = h
+        self._cb = None
+        if detokenizer is not None:
+            def cb(_user, toks, n, out, cap):
+                s = detokenizer([toks[i] for i in range(n)]).encode()
+                if len(s) > cap:
+                    return -1
+                C.memmove(out, s, len(s))
+                return len(s)
+            self._cb = DETOK_FN(cb)
+            self.lib.dsm_worker_set_detokenizer(self.h, self._cb, None)
+
+    def _err(self):
+        return self.lib.dsm_worker_last_error(self.h).decode()
+
+    def open(self):
+        cid = C.c_uint64(0)
+        slot = self.lib.dsm_worker_open(self.h, C.byref(cid))
+        if slot < 0:
+            raise DsmError(self._err())
+        return slot
+
+    def close_channel(self, slot):
+        self.lib.dsm_worker_close(self.h, slot)
+
+    def send(self, slot, raw):
+        rc = self.lib.dsm_worker_send(self.h, slot, raw, len(raw))
+        if rc < 0:
+            raise DsmError(self._err())
+        return rc == 0
+
+    def step(self):
+        rc = self.lib.dsm_worker_step(self.h)
+        if rc < 0:
+            raise DsmError(self._err())
+        return rc == 1
+
+    def recv(self, slot):
+        """All pending OutMsg of the slot, decoded."""
+        out, buf, n = [], np.zeros(1 << 16, dtype=np.uint8), C.c_size_t(0)
+        while self.lib.dsm_worker_recv(self.h, slot, _ptr(buf), buf.size, C.byref(n)) == 1:
+            out.append(decode_out_msg(buf[:n.value].tobytes()))
+        return out
+
+    def buffered(self, slot):
+        return self.lib.dsm_worker_buffered(self.h, slot)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.dsm_worker_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def wav_decode(data):

@@ -878,3 +878,4 @@ int run_conv(dsm_engine* e, hipStream_t st, const ConvGeom& c, const float* cat,
 #include "dsm_engine_api.inc"
 #include "dsm_tts.inc"
 #include "dsm_audio.inc"
+#include "dsm_worker.inc"

@@ -287,6 +287,76 @@ dsm_resampler* dsm_linear_resampler_new(uint32_t in_rate_hz, uint32_t out_rate_h
 size_t dsm_linear_resampler_process(dsm_resampler*, const float* in, size_t n_in, float* out, size_t out_cap);
 void dsm_linear_resampler_free(dsm_resampler*);
 
+/* ------------------------------------------------------------------------------------------------
+ * Host worker above the engine: moshi-server's BatchedAsr module minus the sockets.
+ * Wire format: rmp_serde "struct map" encoding of the internally tagged enums InMsg / OutMsg (srv/asr.rs:15-34):
+ * a msgpack map whose first entry is "type": <variant>, followed by the variant's fields in declaration order;
+ * usize / i64 in their smallest msgpack integer form, f64 as 0xcb, f32 as 0xca (srv/batched_asr.rs:877-880,969-975;
+ * client/rust/kyutai-client/src/stt/protocol.rs:47-62, whose test vector at :82-97 pins the encoding).
+ * ------------------------------------------------------------------------------------------------ */
+enum { DSM_IN_INIT = 0, DSM_IN_MARKER = 1, DSM_IN_AUDIO = 2, DSM_IN_OGGOPUS = 3, DSM_IN_PING = 4 };
+typedef struct dsm_in_msg {
+  int kind;
+  int64_t id;          /* Marker */
+  const float* pcm;    /* Audio */
+  size_t n_pcm;
+  const uint8_t* data; /* OggOpus */
+  size_t n_data;
+} dsm_in_msg;
+enum { DSM_OUT_WORD = 0, DSM_OUT_ENDWORD = 1, DSM_OUT_MARKER = 2, DSM_OUT_STEP = 3, DSM_OUT_ERROR = 4, DSM_OUT_READY = 5 };
+typedef struct dsm_out_msg {
+  int kind;
+  const char* text;      /* Word.text / Error.message (UTF-8, NUL terminated) */
+  double time;           /* Word.start_time / EndWord.stop_time */
+  int64_t id;            /* Marker */
+  uint64_t step_idx;     /* Step */
+  const float* prs;
+  size_t n_prs;
+  uint64_t buffered_pcm;
+} dsm_out_msg;
+/* Encoders return the encoded size (and write it when it fits in cap); decoders return 0 or DSM_ERR_IO. */
+int dsm_inmsg_encode(const dsm_in_msg*, uint8_t* buf, size_t cap);   /* client: protocol.rs encode_in_msg */
+int dsm_outmsg_encode(const dsm_out_msg*, uint8_t* buf, size_t cap); /* server: send_loop serialisation */
+int dsm_inmsg_decode(const uint8_t* bytes, size_t len, dsm_in_msg* out, float* pcm_buf, size_t pcm_cap,
+                     uint8_t* data_buf, size_t data_cap);            /* server: rmp_serde::from_slice::<InMsg> */
+int dsm_outmsg_decode(const uint8_t* bytes, size_t len, dsm_out_msg* out, char* text_buf, size_t text_cap,
+                      float* prs_buf, size_t prs_cap);               /* client: protocol.rs decode_out_msg */
+
+/* text_tokenizer.decode_piece_ids (srv/batched_asr.rs:667): write the UTF-8 text of the pieces, return its length or <0.
+ * Without one a Word carries the decimal piece ids separated by spaces. */
+typedef int (*dsm_detok_fn)(void* user, const uint32_t* tokens, int n_tokens, char* out, size_t cap);
+
+typedef struct dsm_worker dsm_worker;
+int dsm_worker_create(dsm_engine*, dsm_worker** out);  /* slot table of batch_size channels (srv/batched_asr.rs:762-790) */
+/* The four moshi-core calls the worker makes (encode_step :362, reset_batch_idx :468, step_tokens :476 + its
+ * Vec<AsrMsg>), as a table, so that the worker logic can be driven by something other than the HIP engine (the
+ * test-suite plugs the CPU oracle in here; the product path is dsm_worker_create). */
+typedef struct dsm_worker_backend {
+  void* self;
+  int batch_size, asr_delay_in_tokens, extra_heads_num;
+  int (*encode_step)(void* self, const float* pcm /*[B*1920]*/, const uint8_t* mask /*[B]*/); /* codes stay inside */
+  int (*reset_slot)(void* self, int slot);
+  int (*step_tokens)(void* self, const uint8_t* mask, uint32_t* text_tokens_out /*[B]*/, float* prs_out /*[heads*B]*/);
+  int (*poll_msgs)(void* self, dsm_asr_msg* msgs, int cap, uint32_t* tokens_out, int tokens_cap);
+  const char* (*last_error)(void* self); /* may be NULL */
+} dsm_worker_backend;
+int dsm_worker_create_with_backend(const dsm_worker_backend*, dsm_worker** out);
+void dsm_worker_destroy(dsm_worker*);
+const char* dsm_worker_last_error(const dsm_worker*);
+void dsm_worker_set_detokenizer(dsm_worker*, dsm_detok_fn, void* user);
+/* BatchedAsr::channels (:796-808) + the Init that handle_socket / handle_query send (:833,893).  Returns the slot
+ * (batch_idx) or DSM_ERR_STATE when no slot is free ("Server at capacity - no free channels available", :875). */
+int dsm_worker_open(dsm_worker*, uint64_t* channel_id);
+int dsm_worker_close(dsm_worker*, int slot);           /* the socket went away: the slot is recycled by the next step */
+/* One binary websocket message from the client (recv_loop, :927-951): 0 queued, 1 undecodable and skipped,
+ * DSM_ERR_STATE closed channel / OggOpus (no Opus decoder in this build). */
+int dsm_worker_send(dsm_worker*, int slot, const uint8_t* msgpack, size_t len);
+/* One pass of encoder_loop -> model_loop -> post_process (:314-522): 1 a step ran, 0 idle, <0 engine error. */
+int dsm_worker_step(dsm_worker*);
+/* Next serialised OutMsg for the slot's socket (send_loop, :960-985): 1 written, 0 none; *len = its size. */
+int dsm_worker_recv(dsm_worker*, int slot, uint8_t* buf, size_t cap, size_t* len);
+int dsm_worker_buffered(dsm_worker*, int slot);        /* samples waiting in the channel's queue (Step.buffered_pcm) */
+
 #ifdef __cplusplus
 }
 #endif
