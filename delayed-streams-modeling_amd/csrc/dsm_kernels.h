@@ -352,6 +352,9 @@ __global__ void gemm_mfma_kernel(GemmArgs a) {
 // per block).  chunks == 1: fused epilogue.  chunks > 1: the chunk's partial tiles go to a workspace slab in
 // MFMA register layout and gemm_reduce_kernel sums the slabs left to right (canonical order) and runs the epilogue.
 #define DSM_XS_LD 36
+#ifndef DSM_TILE_ABL  // experiments/gemm_tile_ablate.hip compiles parts of the kernel out to price them (timing only)
+#define DSM_TILE_ABL 0
+#endif
 template <typename WT, typename KVT, int MT, int NT, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs a) {
   __shared__ __attribute__((aligned(16))) float Xs[2][16 * MT][DSM_XS_LD];
@@ -402,30 +405,36 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs a) {
   Raw8<WT> rw##I[NT];                                                                  \
   {                                                                                    \
     const int kb_ = k0 + 32 * ((I) < nkb ? (I) : nkb - 1);                             \
+    if (DSM_TILE_ABL & 1) { xp##I = make_float4(1.f, 2.f, 3.f, 4.f); xq##I = xp##I; } else {                  \
     xp##I = *reinterpret_cast<const float4*>(xsrc0 + kb_);                             \
-    xq##I = TWO ? *reinterpret_cast<const float4*>(xsrc1 + kb_) : xp##I;               \
-    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) rw##I[nt].load(wrow[nt] + kb_);  \
+    xq##I = TWO ? *reinterpret_cast<const float4*>(xsrc1 + kb_) : xp##I; }             \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                  \
+      if (DSM_TILE_ABL & 2) rw##I[nt].load(wrow[nt]); else rw##I[nt].load(wrow[nt] + kb_); \
   }
   DSM_FOR8(DSM_LOADBLK)
   __builtin_amdgcn_sched_barrier(0);  // all requests issued before the first block waits for its own
 #define DSM_BLOCK(I)                                                                   \
   if ((I) < nkb) { /* workgroup-uniform */                                             \
     float* xs = &Xs[(I) & 1][0][0];                                                    \
+    if (!(DSM_TILE_ABL & 4)) {                                                         \
     if (has0) *reinterpret_cast<float4*>(xs + xdst0) = xp##I;                          \
-    if (TWO) *reinterpret_cast<float4*>(xs + xdst1) = xq##I;                           \
-    __syncthreads();                                                                   \
+    if (TWO) *reinterpret_cast<float4*>(xs + xdst1) = xq##I; }                         \
+    if (!(DSM_TILE_ABL & 8)) __syncthreads();                                          \
     float wa[NT][8];                                                                   \
     _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) rw##I[nt].unpack(wa[nt]);        \
     float xb[MT][8];                                                                   \
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                \
       const float* fp = xs + (16 * mt + r) * DSM_XS_LD + 8 * q;                        \
-      float4 f0 = *reinterpret_cast<const float4*>(fp), f1 = *reinterpret_cast<const float4*>(fp + 4); \
+      float4 f0, f1;                                                                   \
+      if (DSM_TILE_ABL & 4) { f0 = xp##I; f1 = xq##I; f0.x += mt; } else {             \
+      f0 = *reinterpret_cast<const float4*>(fp); f1 = *reinterpret_cast<const float4*>(fp + 4); } \
       xb[mt][0] = f0.x; xb[mt][1] = f0.y; xb[mt][2] = f0.z; xb[mt][3] = f0.w;          \
       xb[mt][4] = f1.x; xb[mt][5] = f1.y; xb[mt][6] = f1.z; xb[mt][7] = f1.w;          \
     }                                                                                  \
     _Pragma("unroll") for (int s = 0; s < 8; ++s) {                                    \
       _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                \
       _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                \
+        if (DSM_TILE_ABL & 16) acc[nt][mt][0] += wa[nt][s] * xb[mt][s]; else           \
           acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nt][s], xb[mt][s], acc[nt][mt], 0, 0, 0); \
       if (NT * MT > 1) __builtin_amdgcn_sched_barrier(0); /* round-robin over the accumulators */ \
     }                                                                                  \
@@ -435,6 +444,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs a) {
 #undef DSM_LOADBLK
 #undef DSM_BLOCK
 
+  if ((DSM_TILE_ABL & 32) && acc[0][0][0] != 1234.5f) return;
   if (chunks > 1) {
     // slab[chunk][m][n] f32, row-major with ld = ws_ntiles*16: a lane stores its 4 consecutive n of row m
     const long ld = (long)a.ws_ntiles * 16;
