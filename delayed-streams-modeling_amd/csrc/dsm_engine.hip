@@ -184,6 +184,7 @@ struct dsm_engine {
   hipStream_t s_grp[kMaxGroups] = {nullptr, nullptr, nullptr, nullptr};  // s_grp[0] is unused (group 0 runs on s_model)
   hipEvent_t ev_fork = nullptr, ev_grp_in[kMaxGroups] = {}, ev_grp_done[kMaxGroups] = {};
   bool grp_busy = false;
+  int prio_hi = 0;
   bool serialize_groups = false;  // dsm_debug_serialize_groups: every group on the model stream (profiling aid)
   hipEvent_t ev_codes_consumed = nullptr;
   bool codes_consumed_valid = false;
