@@ -759,7 +759,9 @@ int launch_gemm_tiled(dsm_engine* e, hipStream_t st, GemmArgs& a) {
   const bool rows_ok = (EPI == EPI_STORE) && a.norm_out && a.vec && !a.Y2 && a.Y && a.N <= 4096 && a.ymap.bstride == 0;
   if (chunks > 1) {
     if (rows_ok) {
-      hipLaunchKernelGGL(gemm_reduce_rows_kernel, dim3(a.M), dim3(256), 0, st, a, chunks);
+      if (a.N <= 1024) hipLaunchKernelGGL(gemm_reduce_rows_kernel<1>, dim3(a.M), dim3(256), 0, st, a, chunks);
+      else if (a.N <= 2048) hipLaunchKernelGGL(gemm_reduce_rows_kernel<2>, dim3(a.M), dim3(256), 0, st, a, chunks);
+      else hipLaunchKernelGGL(gemm_reduce_rows_kernel<4>, dim3(a.M), dim3(256), 0, st, a, chunks);
     } else {
       const int out_tiles = mtiles * ((a.N + 15) / 16);
       hipLaunchKernelGGL((gemm_reduce_kernel<KVT, EPI>), dim3((out_tiles + 3) / 4), dim3(256), 0, st, a, chunks);

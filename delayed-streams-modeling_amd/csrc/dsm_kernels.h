@@ -569,6 +569,7 @@ __device__ __forceinline__ void row_norm_apply(const float4 (&v)[DSM_ROW_ITS], f
 // Ordered split-K reduce + STORE epilogue (bias / act / scale / residual) + the row norm that follows it, one
 // workgroup per output row (N = d_model).  Same per-element arithmetic as epi_store_qkv<EPI_STORE> followed by
 // row_norm_kernel.
+template <int ITS>  // 1024-element groups per row: ceil(d / 1024) rounded up to 1, 2 or 4
 __global__ __launch_bounds__(256) void gemm_reduce_rows_kernel(GemmArgs a, int chunks) {
   __shared__ float red[8];
   const int m = blockIdx.x;
@@ -579,13 +580,38 @@ __global__ __launch_bounds__(256) void gemm_reduce_rows_kernel(GemmArgs a, int c
   float* yp = a.Y + a.ymap.off(m);
   float4 v[DSM_ROW_ITS];
   float s = 0.0f, s2 = 0.0f;
+  // ordered slab sums of the thread's (up to) four 4-element groups, the loads of all groups and of eight chunks in
+  // flight together: with one group at a time the 22-chunk ff_out reduce was six dependent load rounds
+  f32x4 t[ITS];
+  int off[ITS];  // clamped element offset: a group beyond d re-reads the thread's first group and is dropped
 #pragma unroll
-  for (int it = 0; it < DSM_ROW_ITS; ++it) {
+  for (int it = 0; it < ITS; ++it) {
     const int i = it * 1024 + 4 * (int)threadIdx.x;
-    v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    off[it] = i < d ? i : 4 * (int)threadIdx.x;
+    t[it] = *reinterpret_cast<const f32x4*>(p + off[it]);
+  }
+  for (int c0 = 1; c0 < chunks; c0 += 8) {
+    f32x4 w[ITS][8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int c = c0 + u < chunks ? c0 + u : chunks - 1;  // clamped duplicate load, discarded below
+#pragma unroll
+      for (int it = 0; it < ITS; ++it) w[it][u] = *reinterpret_cast<const f32x4*>(p + off[it] + c * cstride);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (c0 + u < chunks) {
+#pragma unroll
+        for (int it = 0; it < ITS; ++it) t[it] = t[it] + w[it][u];
+      }
+  }
+#pragma unroll
+  for (int it = 0; it < DSM_ROW_ITS; ++it) v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int it = 0; it < ITS; ++it) {
+    const int i = it * 1024 + 4 * (int)threadIdx.x;
     if (i < d) {
-      f32x4 t = slab_sum(p + i, cstride, chunks);
-      float o[4] = {t[0], t[1], t[2], t[3]};
+      float o[4] = {t[it][0], t[it][1], t[it][2], t[it][3]};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (a.bias) o[j] = o[j] + a.bias[i + j];
