@@ -286,7 +286,14 @@ struct dsm_engine {
     void* p = nullptr;
     size_t bytes = count * sizeof(T) + 256;  // slack: K-padding reads of the GEMM may run past a row
     HIPCHK_E(this, hipMalloc(&p, bytes));
-    if (zero) HIPCHK_E(this, hipMemset(p, 0, bytes));
+    // hipMemset / hipMemcpy run on the null stream and may return before the device side is done (a pageable H2D copy
+    // returns once the data is staged); the engine's streams are non-blocking, i.e. NOT ordered against the null
+    // stream, so a kernel launched right after (load-time table folds, state fills) could read or be overwritten by
+    // them.  Load time only: wait.
+    if (zero) {
+      HIPCHK_E(this, hipMemset(p, 0, bytes));
+      HIPCHK_E(this, hipStreamSynchronize(nullptr));
+    }
     allocs.push_back(p);
     *out = reinterpret_cast<T*>(p);
     return 0;
@@ -295,6 +302,7 @@ struct dsm_engine {
   int upload(T** out, const T* host, size_t count) {
     if (int rc = dalloc(out, count)) return rc;
     HIPCHK_E(this, hipMemcpy(*out, host, count * sizeof(T), hipMemcpyHostToDevice));
+    HIPCHK_E(this, hipStreamSynchronize(nullptr));
     return 0;
   }
 };
