@@ -81,3 +81,26 @@ def test_tts_errors(gpu, dsm, lib, tts):
     eng.close()
     with pytest.raises(dsm.DsmError):
         dsm.TtsEngine(cfg, 1, path + ".missing")
+
+
+def test_tts_engine_creation_is_race_free(gpu, dsm, lib, orc, tts):
+    """Regression for a load-time race: the low-rank depformer tables are folded by a GEMM on the engine's
+    (non-blocking) stream right after their operands are uploaded on the null stream; without an explicit wait the fold
+    could read a half-landed upload and one (slice, token) embedding row came out wrong, once in many runs.  Recreate
+    the engine several times over deliberately dirtied device memory and compare the first depformer steps."""
+    import torch
+    cfg, path = tts
+    B = 4
+    ora = orc.OracleTts(cfg, B, path)
+    want = [ora.step(prev, allowed, mask) for prev, allowed, mask in schedule(cfg, B, 6)]
+    ora.close()
+    for trial in range(8):
+        junk = [torch.full(((3 + trial) << 20,), float("nan"), device="cuda") for _ in range(3)]
+        del junk
+        torch.cuda.empty_cache()
+        eng = dsm.TtsEngine(cfg, B, path)
+        for s, (prev, allowed, mask) in enumerate(schedule(cfg, B, 6)):
+            te, ae = eng.step(prev, allowed, mask)
+            act = mask.astype(bool)
+            assert np.array_equal(te[act], want[s][0][act]) and np.array_equal(ae[act], want[s][1][act]), (trial, s)
+        eng.close()
