@@ -78,6 +78,7 @@ def bench_decode(args, eng, cfg, B, dev, world, rank, dist, torch):
     codes = torch.from_numpy(rng.integers(0, cfg.mimi.quantizer_bins, (16, B, n_q)).astype(np.int32)).to(dev)
     mask = torch.ones(B, dtype=torch.uint8, device=dev)
     pcm = torch.zeros(B * 1920, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
     it = 0
     if args.fast_fill or not args.no_fill:
         for _ in range(cfg.mimi.transformer.context // 2 + 4):  # decoder transformer ring (250 @ 25 Hz) full
@@ -210,6 +211,7 @@ def main():
     text = torch.zeros(B, dtype=torch.int32, device=dev)
     prs = torch.zeros(max(cfg.extra_heads_num, 1) * B, dtype=torch.float32, device=dev)
     codes = torch.zeros(B * cfg.audio_codebooks, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()  # uploads above ran on torch's stream; the engine's streams are not ordered against it
 
     def step(i):
         if args.no_overlap:  # everything on one stream (asr::State::step_pcm)

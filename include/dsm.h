@@ -194,7 +194,10 @@ int dsm_n_q(const dsm_engine*); /* mimi.config().quantizer_n_q — srv/batched_a
 /*
  * Device-resident variants for callers that already hold HBM buffers (bench.py's timed
  * region; a Rust caller with hipMalloc'd staging).  Pointers are DEVICE pointers, nothing
- * is synchronised; work is enqueued on the engine's encoder / model stream.
+ * is synchronised; work is enqueued on the engine's encoder / model / group streams, which are
+ * NON-BLOCKING: they are not ordered against the null stream or the caller's streams.  The caller
+ * makes its inputs visible before the call (stream/device synchronise after filling them) and
+ * reads outputs only after dsm_sync; inputs must stay unmodified until then.
  */
 int dsm_mimi_encode_step_dev(dsm_engine*, const float* d_pcm, const uint8_t* d_mask, uint32_t* d_codes_out);
 int dsm_asr_step_tokens_dev(dsm_engine*, const uint32_t* d_codes, const uint8_t* d_mask,

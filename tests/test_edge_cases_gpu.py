@@ -118,6 +118,7 @@ def test_stream_groups_do_not_change_results(gpu, dsm, lib, orc, tiny_weights, m
         else:  # device-pointer entry: nothing synchronised, groups keep running into the next call
             d_pcm = torch.from_numpy(pcm[s]).to(dev)
             d_mask = torch.from_numpy(masks[s]).to(dev)
+            torch.cuda.synchronize()  # torch's stream is not ordered against the engine's non-blocking streams
             eng.step_pcm_dev(d_pcm.data_ptr(), d_mask.data_ptr(), d_codes.data_ptr(), d_text.data_ptr(), d_prs.data_ptr())
             eng.sync()
             ec = d_codes.cpu().numpy().astype(np.uint32).reshape(B, -1)
