@@ -28,20 +28,28 @@ def route(stream_id, shards):
     raise IndexError(stream_id)
 
 
-def broadcast_bytes(raw, src, dist, device=None):
-    """Broadcast a uint8 numpy array from rank `src` to every rank of the default process group.
-    Two collectives (length, payload); returns the bytes as a numpy array on every rank."""
+def broadcast_bytes(raw, src, dist, device=None, chunk_bytes=512 << 20):
+    """Broadcast a uint8 numpy array from rank `src` to every rank of the default process group: one collective for
+    the length, then the payload in pieces of `chunk_bytes` (a 5 GB checkpoint stays far from any 2^31 element limit
+    and needs only one chunk of device staging).  Returns the bytes as a numpy array on every rank."""
     import torch
     rank = dist.get_rank()
     dev = device if device is not None else torch.device("cpu")
     n = torch.tensor([raw.size if rank == src else 0], dtype=torch.int64, device=dev)
     dist.broadcast(n, src)
-    if rank == src:
-        buf = torch.from_numpy(np.ascontiguousarray(raw)).to(dev)
-    else:
-        buf = torch.empty(int(n.item()), dtype=torch.uint8, device=dev)
-    dist.broadcast(buf, src)
-    return buf.cpu().numpy()
+    total = int(n.item())
+    out = np.ascontiguousarray(raw) if rank == src else np.empty(total, dtype=np.uint8)
+    for lo in range(0, total, chunk_bytes):
+        hi = min(total, lo + chunk_bytes)
+        if rank == src:
+            buf = torch.from_numpy(out[lo:hi]).to(dev)
+        else:
+            buf = torch.empty(hi - lo, dtype=torch.uint8, device=dev)
+        dist.broadcast(buf, src)
+        if rank != src:
+            out[lo:hi] = buf.cpu().numpy()
+        del buf
+    return out
 
 
 def digest(raw):

@@ -35,7 +35,7 @@ WORKER = textwrap.dedent("""
     paths = []
     for which in ("lm", "mimi"):
         raw = np.fromfile(os.path.join(wdir, "tiny.%s.safetensors" % which), dtype=np.uint8) if rank == 0 else np.zeros(0, np.uint8)
-        got = sharding.broadcast_bytes(raw, 0, dist)
+        got = sharding.broadcast_bytes(raw, 0, dist, chunk_bytes=300000)  # several pieces (the files are ~1 MB)
         p = os.path.join(wdir, "shard_test.rank%d.%s.safetensors" % (rank, which))
         got.tofile(p)
         paths.append(p)
