@@ -285,7 +285,12 @@ def main():
         # algorithmic bytes of the attention launches of ONE layer: K and V of every (slot, head) once + q in + out.
         # The LM step runs the batch as len(groups) stream groups, each with its own attention launch per layer, so a
         # launch covers B / len(groups) slots on average and `achieved` is bytes of all timed launches / their time.
-        attn_bytes_layer = B * H * (2 * fill * hd * kv_b + 2 * hd * 4)
+        # Fused prologue (default, DSM_FUSE_QKV): the launch also sums the QKV GEMM's split-K slabs for its 3*hd values
+        # (chunks = d/256 partials each, f32) and writes the new K/V row, instead of reading q.
+        fused = os.environ.get("DSM_FUSE_QKV", "1") != "0"
+        chunks = (cfg.lm.d_model + 255) // 256
+        per_head = 2 * fill * hd * kv_b + hd * 4 + ((3 * hd * 4 * chunks + 2 * hd * kv_b) if fused else hd * 4)
+        attn_bytes_layer = B * H * per_head
         attn_bytes = attn_bytes_layer / len(groups)
         # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (bench.py cannot run under --pmc and
         # time itself): 2 x FETCH_SIZE (gfx950 counts 64 B per 128-B request) + WRITE_SIZE, per dispatch
@@ -325,8 +330,8 @@ def main():
                        "streams_per_gpu": B, "parallelism": "replicas x%d (independent stream batches)" % world,
                        "streams": "single stream" if args.no_overlap else "encoder stream || %d LM group stream(s)" % len(groups),
                        "weights_broadcast_ms": bcast_ms},
-            "roofline": {"bound": "hbm", "kernel": "attn_kernel<bf16,hd%d,T1> (LM ring-cache attention, %d launches/step: %d layers x %d stream groups of %s slots)"
-                                                    % (hd, L * len(groups), L, len(groups), "/".join(str(n) for _, n in groups)),
+            "roofline": {"bound": "hbm", "kernel": "attn_kernel<bf16,hd%d,T1> (LM ring-cache attention%s, %d launches/step: %d layers x %d stream groups of %s slots)"
+                                                    % (hd, " with the fused QKV reduce + RoPE + ring scatter prologue" if fused else "", L * len(groups), L, len(groups), "/".join(str(n) for _, n in groups)),
                          "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "algorithmic_bytes_per_launch": attn_bytes, "avg_launch_us": attn_avg_us,
                          "launches_timed": int(attn_n), "timer": "device wall clock inside the kernel (agrees with rocprofv3 --kernel-trace)",

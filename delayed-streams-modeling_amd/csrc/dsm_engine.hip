@@ -184,6 +184,7 @@ struct dsm_engine {
   hipStream_t s_grp[kMaxGroups] = {nullptr, nullptr, nullptr, nullptr};  // s_grp[0] is unused (group 0 runs on s_model)
   hipEvent_t ev_fork = nullptr, ev_grp_in[kMaxGroups] = {}, ev_grp_done[kMaxGroups] = {};
   bool grp_busy = false;
+  bool fuse_qkv = true;  // DSM_FUSE_QKV=0: keep the separate QKV reduce launch
   int prio_hi = 0;
   bool serialize_groups = false;  // dsm_debug_serialize_groups: every group on the model stream (profiling aid)
   hipEvent_t ev_codes_consumed = nullptr;
@@ -765,7 +766,7 @@ int launch_gemm_tiled(dsm_engine* e, hipStream_t st, GemmArgs& a) {
   else
     hipLaunchKernelGGL((gemm_tile_kernel<WT, KVT, 1, NT, EPI>), grid, dim3(256), 0, st, a);
   const bool rows_ok = (EPI == EPI_STORE) && a.norm_out && a.vec && !a.Y2 && a.Y && a.N <= 4096 && a.ymap.bstride == 0;
-  if (chunks > 1) {
+  if (chunks > 1 && !(EPI == EPI_QKV && a.defer_reduce)) {
     if (rows_ok) {
       if (a.N <= 1024) hipLaunchKernelGGL(gemm_reduce_rows_kernel<1>, dim3(a.M), dim3(256), 0, st, a, chunks);
       else if (a.N <= 2048) hipLaunchKernelGGL(gemm_reduce_rows_kernel<2>, dim3(a.M), dim3(256), 0, st, a, chunks);

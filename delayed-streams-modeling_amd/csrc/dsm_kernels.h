@@ -67,6 +67,7 @@ struct GemmArgs {
   // split-K workspace of the tiled kernel: [chunks][M padded to 16][ws_ntiles*16] f32, row-major
   float* ws;
   int ws_ntiles;
+  int defer_reduce;  // EPI_QKV, T = 1: leave the slabs to the attention kernel's prologue (AttnFused)
   // optional row norm fused behind an EPI_STORE GEMM whose N is d_model (gemm_reduce_rows_kernel)
   const float* norm_w;
   const float* norm_b;
@@ -669,12 +670,23 @@ __global__ __launch_bounds__(256) void row_norm_kernel(float* __restrict__ y, co
 // One workgroup (4 waves) per (slot b, head h).  LPK = HD/8 lanes per key, G = 64/LPK keys per
 // wave-instruction, key j -> wave (j/G)%4, lane group j%G (canonical order, dsm_numerics.h).
 // ------------------------------------------------------------------------------------------
+// T = 1 only: the QKV GEMM left its split-K slabs in place and this kernel finishes the job for its own (slot, head) —
+// ordered slab sums of the 3 x HD values, RoPE on q and k, K/V rows rounded into the ring cache at widx — before it
+// attends.  Same arithmetic, same order as gemm_reduce_kernel<KVT, EPI_QKV>; one launch and the q round trip less.
+struct AttnFused {
+  const float* ws;  // null: q comes from qbuf, K/V are already in the cache
+  long ld, cstride;
+  int chunks;
+  const float* rope_cs;
+  const uint32_t* widx;
+};
+
 template <typename KVT, int HD, int T>
 __global__ __launch_bounds__(256, 4) void attn_kernel(float* __restrict__ out, const float* __restrict__ qbuf,
                                                    const KVT* __restrict__ kcache, const KVT* __restrict__ vcache,
                                                    const uint32_t* __restrict__ start_pos,
                                                    const uint8_t* __restrict__ active, int H, int ctx, int d,
-                                                   unsigned long long* __restrict__ ts) {
+                                                   unsigned long long* __restrict__ ts, AttnFused fq) {
   constexpr int NW = 4, LPK = HD / 8, G = 64 / LPK;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int b = blockIdx.x / H, h = blockIdx.x % H;
@@ -696,16 +708,48 @@ __global__ __launch_bounds__(256, 4) void attn_kernel(float* __restrict__ out, c
   const int nvalid = (int)((e1 + 1 < (long)ctx) ? e1 + 1 : ctx);  // slots > e1 were never written
   const float scale = (float)(1.0 / sqrt((double)HD));
 
+  const KVT* Kb = kcache + ((long)b * H + h) * ctx * HD;
+  const KVT* Vb = vcache + ((long)b * H + h) * ctx * HD;
+  if (T == 1 && fq.ws) {
+    // row m = b of the [M][3d] QKV product: q at n = h*HD + i, k at d + ..., v at 2d + ... (core/batched_transformer.rs:77-82)
+    if (tid < 3 * HD / 4) {
+      const int part = tid / (HD / 4), i0 = 4 * (tid % (HD / 4));
+      const f32x4 v = slab_sum(fq.ws + (long)b * fq.ld + part * d + h * HD + i0, fq.cstride, fq.chunks);
+      float o[4] = {v[0], v[1], v[2], v[3]};
+      if (part < 2 && fq.rope_cs) {  // rope_i on interleaved pairs — core/transformer.rs:373-377
+        const float4 cs = *reinterpret_cast<const float4*>(fq.rope_cs + ((long)b * (HD / 2) + (i0 >> 1)) * 2);
+        const float co[2] = {cs.x, cs.z}, si[2] = {cs.y, cs.w};
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          float x0 = v[2 * p], x1 = v[2 * p + 1];
+          float t0 = x0 * co[p], t1 = x1 * si[p], t2 = x0 * si[p], t3 = x1 * co[p];
+          o[2 * p] = t0 - t1;
+          o[2 * p + 1] = t2 + t3;
+        }
+      }
+      if (part == 0) {
+        red[i0] = o[0]; red[i0 + 1] = o[1]; red[i0 + 2] = o[2]; red[i0 + 3] = o[3];  // q staged in the (still unused) red area; ctx*4 B is not a multiple of 16: scalar accesses
+      } else {
+        KVT* row = const_cast<KVT*>(part == 1 ? Kb : Vb) + (long)fq.widx[b] * HD + i0;
+        store_kv4(row, o);
+      }
+    }
+    __syncthreads();  // q visible in LDS; this workgroup's K/V row visible to its own loads below
+  }
   float qv[T][8];
 #pragma unroll
   for (int t = 0; t < T; ++t) {
-    const float* qp = qbuf + ((long)(b * T + t)) * d + h * HD + 8 * li;
-    float4 q0 = *reinterpret_cast<const float4*>(qp), q1 = *reinterpret_cast<const float4*>(qp + 4);
-    qv[t][0] = q0.x; qv[t][1] = q0.y; qv[t][2] = q0.z; qv[t][3] = q0.w;
-    qv[t][4] = q1.x; qv[t][5] = q1.y; qv[t][6] = q1.z; qv[t][7] = q1.w;
+    if (T == 1 && fq.ws) {
+#pragma unroll
+      for (int dd = 0; dd < 8; ++dd) qv[t][dd] = red[8 * li + dd];
+    } else {
+      const float* qp = qbuf + ((long)(b * T + t)) * d + h * HD + 8 * li;
+      float4 q0 = *reinterpret_cast<const float4*>(qp), q1 = *reinterpret_cast<const float4*>(qp + 4);
+      qv[t][0] = q0.x; qv[t][1] = q0.y; qv[t][2] = q0.z; qv[t][3] = q0.w;
+      qv[t][4] = q1.x; qv[t][5] = q1.y; qv[t][6] = q1.z; qv[t][7] = q1.w;
+    }
   }
-  const KVT* Kb = kcache + ((long)b * H + h) * ctx * HD;
-  const KVT* Vb = vcache + ((long)b * H + h) * ctx * HD;
+  if (T == 1 && fq.ws) __syncthreads();  // every lane holds its q before `red` is reused for the partial outputs
 
   // ---- phase 1: scores.  Software-pipelined: while one batch of UNR keys per lane is reduced, the next batch's
   // 16-byte loads are already in flight (raw cache words, converted at use), so a wave keeps UNR..2*UNR loads
