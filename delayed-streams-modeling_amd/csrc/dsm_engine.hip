@@ -185,6 +185,7 @@ struct dsm_engine {
   hipEvent_t ev_fork = nullptr, ev_grp_in[kMaxGroups] = {}, ev_grp_done[kMaxGroups] = {};
   bool grp_busy = false;
   bool fuse_qkv = true;  // DSM_FUSE_QKV=0: keep the separate QKV reduce launch
+  bool chunk_loop = true;  // DSM_CHUNK_LOOP=0: always split K across workgroups
   int prio_hi = 0;
   bool serialize_groups = false;  // dsm_debug_serialize_groups: every group on the model stream (profiling aid)
   hipEvent_t ev_codes_consumed = nullptr;
@@ -734,8 +735,17 @@ int alloc_mimi_state(dsm_engine* e, MimiState* s, const MimiW& w, int B) {
 // ----------------------------------------------------------------------------------------------
 template <typename WT, typename KVT, int EPI, int NT>
 int launch_gemm_tiled(dsm_engine* e, hipStream_t st, GemmArgs& a) {
-  const int chunks = (a.Kpad + DSM_KC - 1) / DSM_KC;
+  int chunks = (a.Kpad + DSM_KC - 1) / DSM_KC;
   const int gx = (a.N + 63) / 64;
+  // Enough (n, m) tiles to fill the chip three times over (large batches; the Mimi convs, whose M is B x frames): no
+  // split-K across workgroups — each walks the chunks itself and sums them in order in registers, so the slabs
+  // (chunks x M x N floats written, then read back by a reduce launch) disappear.
+  a.chunk_loop = 0;
+  if (chunks > 1 && e->chunk_loop && (long)gx * ((a.M + 63) / 64) >= 768) {
+    a.chunk_loop = chunks;
+    a.defer_reduce = 0;
+    chunks = 1;
+  }
   int MT = a.M > 32 ? 4 : (a.M > 16 ? 2 : 1);
   while (MT > 1 && (long)gx * chunks * ((a.M + 16 * MT - 1) / (16 * MT)) < 256) MT /= 2;  // cover the 256 CUs
   auto ok4 = [](const RowMap& m) { return m.ld % 4 == 0 && m.bstride % 4 == 0; };

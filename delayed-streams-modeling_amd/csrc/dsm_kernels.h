@@ -68,6 +68,8 @@ struct GemmArgs {
   float* ws;
   int ws_ntiles;
   int defer_reduce;  // EPI_QKV, T = 1: leave the slabs to the attention kernel's prologue (AttnFused)
+  int chunk_loop;    // > 1: one workgroup walks all K-chunks itself (grid.y = 1) and adds the chunk sums left to right in
+                     // registers — no slabs, no reduce launch; chosen when the (n, m) tiles alone fill the chip
   // optional row norm fused behind an EPI_STORE GEMM whose N is d_model (gemm_reduce_rows_kernel)
   const float* norm_w;
   const float* norm_b;
@@ -361,12 +363,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs a) {
   __shared__ __attribute__((aligned(16))) float Xs[2][16 * MT][DSM_XS_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
-  const int chunk = blockIdx.y, chunks = gridDim.y;
+  const int chunks = gridDim.y;  // split-K across workgroups; 1 when a.chunk_loop walks the chunks below
   const int m_base = blockIdx.z * (16 * MT);
   const int n_base = blockIdx.x * 64 + 16 * wave;  // this wave's n-tile
   const WT* W = reinterpret_cast<const WT*>(a.W);
-  const int k0 = chunk * DSM_KC;
-  const int k1 = min(k0 + DSM_KC, a.Kpad);
 
   const WT* wrow[NT];
 #pragma unroll
@@ -386,7 +386,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs a) {
   const float* xsrc1 = a.X + a.xmap.off(m1) + 4 * part;
   const int xdst1 = (row0 + 32) * DSM_XS_LD + 4 * part;
 
-  f32x4 acc[NT][MT];
+  const int nloop = a.chunk_loop > 1 ? a.chunk_loop : 1;
+  f32x4 acc[NT][MT], tot[NT][MT];
+  for (int cl = 0; cl < nloop; ++cl) {
+  const int chunk = a.chunk_loop > 1 ? cl : (int)blockIdx.y;
+  const int k0 = chunk * DSM_KC;
+  const int k1 = min(k0 + DSM_KC, a.Kpad);
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -444,6 +449,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs a) {
 #undef DSM_FOR8
 #undef DSM_LOADBLK
 #undef DSM_BLOCK
+  // canonical split-K order: chunk sums added left to right (here in registers, otherwise by the reduce kernels)
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) tot[nt][mt] = cl == 0 ? acc[nt][mt] : tot[nt][mt] + acc[nt][mt];
+  }  // chunk loop
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = tot[nt][mt];
 
   if ((DSM_TILE_ABL & 32) && acc[0][0][0] != 1234.5f) return;
   if (chunks > 1) {
@@ -457,7 +472,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs a) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int n = n_base + nt * a.nt_stride + 4 * q;
-        *reinterpret_cast<f32x4*>(a.ws + ((long)chunk * mpad + m) * ld + n) = acc[nt][mt];
+        *reinterpret_cast<f32x4*>(a.ws + ((long)blockIdx.y * mpad + m) * ld + n) = acc[nt][mt];
       }
     }
     return;

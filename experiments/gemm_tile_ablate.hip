@@ -33,13 +33,14 @@ int main() {
       {"qkv", 6144, 2048, 1, 16}, {"gate", 5632, 2048, 2, 5632}, {"out_proj", 2048, 2048, 1, 16}, {"ff_out", 2048, 5632, 1, 16}};
   const size_t wmax = (size_t)(11264 + 128) * 2048;
   float *X, *ws; uint16_t* W;
-  CK(hipMalloc(&X, (size_t)64 * 5632 * 4)); CK(hipMalloc(&W, wmax * 2 * NBUF)); CK(hipMalloc(&ws, (size_t)22 * 64 * 11264 * 4 + (1 << 20)));
-  std::vector<float> hx((size_t)64 * 5632); for (auto& v : hx) v = (rand() % 2001 - 1000) / 1000.0f;
+  const int MMAX = 512;
+  CK(hipMalloc(&X, (size_t)MMAX * 5632 * 4)); CK(hipMalloc(&W, wmax * 2 * NBUF)); CK(hipMalloc(&ws, (size_t)22 * MMAX * 11264 * 4 + (1 << 20)));
+  std::vector<float> hx((size_t)MMAX * 5632); for (auto& v : hx) v = (rand() % 2001 - 1000) / 1000.0f;
   std::vector<uint16_t> hw(wmax); for (auto& v : hw) v = dsm_f32_to_bf16((rand() % 2001 - 1000) / 1000.0f);
   CK(hipMemcpy(X, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
   for (int i = 0; i < NBUF; ++i) CK(hipMemcpy(W + (size_t)i * wmax, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
   printf("DSM_TILE_ABL=%d\n", DSM_TILE_ABL);
-  for (int M : {64, 32}) {
+  for (int M : {64, 32, 512}) {
     for (auto& s : shapes) {
       GemmArgs a; memset(&a, 0, sizeof a);
       a.X = X; a.xmap.bstride = 0; a.xmap.rpb = M; a.xmap.ld = s.K; a.xmap.toff = 0;
@@ -47,7 +48,7 @@ int main() {
       a.ws_ntiles = (((s.NT - 1) * s.stride) >> 4) + ((s.N + 63) / 64) * 4;
       const double mfma = (double)(s.N * s.NT / 16) * (M / 16) * (s.K / 4);
       float t;
-      if (M == 64) t = s.NT == 2 ? run<4, 2, EPI_GATE>(a, 40, W, wmax, NBUF) : run<4, 1, EPI_STORE>(a, 40, W, wmax, NBUF);
+      if (M >= 64) t = s.NT == 2 ? run<4, 2, EPI_GATE>(a, 40, W, wmax, NBUF) : run<4, 1, EPI_STORE>(a, 40, W, wmax, NBUF);
       else t = s.NT == 2 ? run<2, 2, EPI_GATE>(a, 40, W, wmax, NBUF) : run<2, 1, EPI_STORE>(a, 40, W, wmax, NBUF);
       printf("  M=%2d %-9s ideal MFMA %5.1f us | %6.1f us\n", M, s.name, mfma * 32 / 1024 / 2400.0, t);
     }
