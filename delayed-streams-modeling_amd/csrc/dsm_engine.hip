@@ -186,6 +186,7 @@ struct dsm_engine {
   bool grp_busy = false;
   bool fuse_qkv = true;  // DSM_FUSE_QKV=0: keep the separate QKV reduce launch
   bool chunk_loop = true;  // DSM_CHUNK_LOOP=0: always split K across workgroups
+  int chunk_loop_min_tiles = 384;  // DSM_CHUNK_LOOP_MIN (swept at B = 512 / 1024: 384 best)
   int prio_hi = 0;
   bool serialize_groups = false;  // dsm_debug_serialize_groups: every group on the model stream (profiling aid)
   hipEvent_t ev_codes_consumed = nullptr;
@@ -737,11 +738,11 @@ template <typename WT, typename KVT, int EPI, int NT>
 int launch_gemm_tiled(dsm_engine* e, hipStream_t st, GemmArgs& a) {
   int chunks = (a.Kpad + DSM_KC - 1) / DSM_KC;
   const int gx = (a.N + 63) / 64;
-  // Enough (n, m) tiles to fill the chip three times over (large batches; the Mimi convs, whose M is B x frames): no
+  // Enough (n, m) tiles to fill the chip (large batches; the Mimi convs, whose M is B x frames): no
   // split-K across workgroups — each walks the chunks itself and sums them in order in registers, so the slabs
   // (chunks x M x N floats written, then read back by a reduce launch) disappear.
   a.chunk_loop = 0;
-  if (chunks > 1 && e->chunk_loop && (long)gx * ((a.M + 63) / 64) >= 768) {
+  if (chunks > 1 && e->chunk_loop && (long)gx * ((a.M + 63) / 64) >= e->chunk_loop_min_tiles) {
     a.chunk_loop = chunks;
     a.defer_reduce = 0;
     chunks = 1;

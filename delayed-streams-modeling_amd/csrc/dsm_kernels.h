@@ -707,9 +707,13 @@ __global__ __launch_bounds__(256, 4) void attn_kernel(float* __restrict__ out, c
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   // optional device-clock bracket of the whole launch (dsm_prof_read_device): first workgroup in, last one out.
   // HIP events around a launch also count the time it queues behind other streams' kernels; this does not.
-  if (ts && threadIdx.x == 0) atomicMin(&ts[0], wall_clock64());
+  // Only the first 256 workgroups race for the start stamp and the last 1024 for the end stamp (dispatch is in index
+  // order): thousands of atomics on one address would themselves stretch a large launch.
+  const bool ts_first = ts && threadIdx.x == 0 && blockIdx.x < 256;
+  const bool ts_last = ts && threadIdx.x == 0 && blockIdx.x + 1024 >= gridDim.x;
+  if (ts_first) atomicMin(&ts[0], wall_clock64());
   if (!active[b]) {  // inactive slots: output unused by the reference (core/asr.rs:221-223)
-    if (ts && threadIdx.x == 0) atomicMax(&ts[1], wall_clock64());
+    if (ts_last) atomicMax(&ts[1], wall_clock64());
     return;
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -890,7 +894,7 @@ __global__ __launch_bounds__(256, 4) void attn_kernel(float* __restrict__ out, c
                 red[(3 * T + t) * HD + dd];
     out[((long)(b * T + t)) * d + h * HD + dd] = tot;
   }
-  if (ts && threadIdx.x == 0) atomicMax(&ts[1], wall_clock64());
+  if (ts_last) atomicMax(&ts[1], wall_clock64());
 }
 
 // ------------------------------------------------------------------------------------------
