@@ -129,3 +129,28 @@ def test_stream_groups_do_not_change_results(gpu, dsm, lib, orc, tiny_weights, m
         assert np.array_equal(ep[:, act].view(np.uint32), op[:, act].view(np.uint32)), f"VAD heads differ at step {s}"
     eng.close()
     ora.close()
+
+
+def test_in_workgroup_chunk_loop_on_tiny_shapes(gpu, dsm, lib, orc, tiny_weights, monkeypatch):
+    """DSM_CHUNK_LOOP_MIN=1 sends every multi-chunk GEMM of the tiny model (K = 352: one full and one 3-block chunk)
+    down the in-workgroup chunk loop; tokens, codes and decoded PCM must not move."""
+    from dsm_amd import synth
+    monkeypatch.setenv("DSM_CHUNK_LOOP_MIN", "1")
+    cfg = dsm.config_tiny()
+    B = 5
+    eng = dsm.AsrEngine(cfg, B, *tiny_weights)
+    ora = orc.OracleAsr(cfg, B, *tiny_weights)
+    pcm = synth.synth_pcm(B, 8)
+    rng = np.random.default_rng(9)
+    for s in range(8):
+        mask = (rng.random(B) < 0.8).astype(np.uint8)
+        act = mask.astype(bool)
+        ec, et, ep = eng.step_pcm(pcm[s], mask)
+        oc, ot, op = ora.step_pcm(pcm[s], mask)
+        assert np.array_equal(ec[act], oc[act]) and np.array_equal(et[act], ot[act])
+        assert np.array_equal(ep[:, act].view(np.uint32), op[:, act].view(np.uint32))
+        lg_e = eng.debug_read("lm.logits", B * cfg.text_out_vocab_size).reshape(B, -1)
+        lg_o = ora.debug_read("lm.logits", B * cfg.text_out_vocab_size).reshape(B, -1)
+        assert np.array_equal(lg_e[act].view(np.uint32), lg_o[act].view(np.uint32))
+    eng.close()
+    ora.close()

@@ -16,10 +16,16 @@ def full_weights(dsm):
     return cfg, synth.make_synth_weights(cfg, os.environ.get("DSM_WEIGHTS_DIR", "/tmp/dsm_weights"), tag="stt-1b-en_fr")
 
 
-def test_full_size_encode_lm_and_decode(gpu, dsm, lib, orc, full_weights):
+@pytest.mark.parametrize("chunk_loop_min", [None, "1"])
+def test_full_size_encode_lm_and_decode(gpu, dsm, lib, orc, full_weights, monkeypatch, chunk_loop_min):
+    """chunk_loop_min = "1": every split-K GEMM (LM: 8 and 22 chunks; Mimi convs) walks its chunks inside the workgroup
+    and sums them in registers — the path large batches take (GemmArgs::chunk_loop) — instead of writing slabs for a
+    reduce launch; the QKV prologue fusion falls back to the direct epilogue.  Same bits either way."""
     from dsm_amd import synth
     cfg, (lm, mimi) = full_weights
-    B, steps = 3, 4
+    if chunk_loop_min:
+        monkeypatch.setenv("DSM_CHUNK_LOOP_MIN", chunk_loop_min)
+    B, steps = 3, (4 if chunk_loop_min is None else 2)
     eng = dsm.AsrEngine(cfg, B, lm, mimi)
     ora = orc.OracleAsr(cfg, B, lm, mimi)
     pcm = synth.synth_pcm(B, steps)
