@@ -186,6 +186,7 @@ struct dsm_engine {
   bool grp_busy = false;
   bool fuse_qkv = true;  // DSM_FUSE_QKV=0: keep the separate QKV reduce launch
   bool chunk_loop = true;  // DSM_CHUNK_LOOP=0: always split K across workgroups
+  size_t attn_lds_pad = 60000;  // DSM_ATTN_LDS_PAD: extra dynamic LDS per attention workgroup of a large launch (2 per CU)
   int chunk_loop_min_tiles = 384;  // DSM_CHUNK_LOOP_MIN (swept at B = 512 / 1024: 384 best)
   int prio_hi = 0;
   bool serialize_groups = false;  // dsm_debug_serialize_groups: every group on the model stream (profiling aid)
