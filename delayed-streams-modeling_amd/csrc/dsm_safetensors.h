@@ -116,6 +116,7 @@ static inline int dsm_st__parse_int(const char** p, const char* end, int64_t* ou
   int64_t v = 0;
   int any = 0;
   while (*p < end && **p >= '0' && **p <= '9') {
+    if (v > (INT64_MAX - 9) / 10) return -1; /* a hostile header must not overflow the accumulator */
     v = v * 10 + (**p - '0');
     ++*p;
     any = 1;
@@ -290,7 +291,10 @@ static inline const dsm_st_tensor* dsm_st_find(const dsm_st_file* f, const char*
 
 static inline int64_t dsm_st_numel(const dsm_st_tensor* t) {
   int64_t n = 1;
-  for (int i = 0; i < t->ndim; ++i) n *= t->shape[i];
+  for (int i = 0; i < t->ndim; ++i) {
+    if (t->shape[i] < 0 || (t->shape[i] > 0 && n > INT64_MAX / t->shape[i])) return -1; /* overflow: matches no request */
+    n *= t->shape[i];
+  }
   return n;
 }
 

@@ -172,8 +172,10 @@ int dsm_asr_step_tokens(dsm_engine*, const uint32_t* codes, const uint8_t* mask,
 int dsm_asr_step_pcm(dsm_engine*, const float* pcm, const uint8_t* mask, uint32_t* codes_out,
                      uint32_t* text_tokens_out, float* vad_prs_out);
 
-/* Drain the Vec<AsrMsg> the last step returned.  Returns the number of messages written
- * (<= cap); word tokens are copied to tokens_out (tokens_cap entries). */
+/* Read the Vec<AsrMsg> the last step returned (the list lives until the next step: polling does not consume it).
+ * Returns the number of messages written (<= cap; a step yields at most 2*B + 1); word tokens are copied to
+ * tokens_out, truncated to tokens_cap entries — a Word whose tokens_offset + n_tokens exceeds tokens_cap was cut:
+ * poll again with a larger buffer (dsm_worker_step does exactly that). */
 int dsm_asr_poll_msgs(dsm_engine*, dsm_asr_msg* msgs, int cap, uint32_t* tokens_out, int tokens_cap);
 
 /* asr::State::reset_batch_idx(slot) — core/asr.rs:257-266, srv/batched_asr.rs:467-471.
@@ -351,7 +353,8 @@ void dsm_worker_set_detokenizer(dsm_worker*, dsm_detok_fn, void* user);
  * (batch_idx) or DSM_ERR_STATE when no slot is free ("Server at capacity - no free channels available", :875). */
 int dsm_worker_open(dsm_worker*, uint64_t* channel_id);
 int dsm_worker_close(dsm_worker*, int slot);           /* the socket went away: the slot is recycled by the next step */
-/* One binary websocket message from the client (recv_loop, :927-951): 0 queued, 1 undecodable and skipped,
+/* One binary websocket message from the client (recv_loop, :927-951): 0 queued, 1 undecodable and skipped (malformed,
+ * larger than 64 MiB, or nested deeper than rmp_serde's limit of 1024: the reference logs and carries on),
  * DSM_ERR_STATE closed channel / OggOpus (no Opus decoder in this build). */
 int dsm_worker_send(dsm_worker*, int slot, const uint8_t* msgpack, size_t len);
 /* One pass of encoder_loop -> model_loop -> post_process (:314-522): 1 a step ran, 0 idle, <0 engine error. */

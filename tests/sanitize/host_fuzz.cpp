@@ -1,0 +1,400 @@
+// host_fuzz.cpp — host-only build of the three parsers of untrusted bytes (csrc/dsm_worker.inc: msgpack + worker,
+// csrc/dsm_audio.inc: RIFF/WAVE, csrc/dsm_safetensors.h: checkpoint header) under -fsanitize=address,undefined, driven
+// with truncated, oversized, deeply nested and bit-flipped inputs.  No device code, no engine: the worker runs on a
+// scripted backend.  Build + run: tests/sanitize/Makefile (target `run`), wrapped by tests/test_sanitizers_cpu.py.
+// Exit code 0 = every case was either decoded or rejected cleanly; any sanitizer report aborts (-fno-sanitize-recover).
+#define DSM_HOST_ONLY 1
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/dsm.h"
+static thread_local std::string g_create_error;
+#include "../../delayed-streams-modeling_amd/csrc/dsm_safetensors.h"
+#include "../../delayed-streams-modeling_amd/csrc/dsm_audio.inc"
+#include "../../delayed-streams-modeling_amd/csrc/dsm_worker.inc"
+
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static uint32_t rnd() {
+  rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17;
+  return (uint32_t)(rng_state >> 32);
+}
+static long n_cases = 0;
+#define REQUIRE(c) do { if (!(c)) { fprintf(stderr, "host_fuzz: check failed at line %d: %s\n", __LINE__, #c); exit(3); } } while (0)
+
+using Bytes = std::vector<uint8_t>;
+
+static void try_in(const Bytes& b) {
+  dsm_in_msg m;
+  std::vector<float> pcm(64);
+  std::vector<uint8_t> data(64);
+  (void)dsm_inmsg_decode(b.data(), b.size(), &m, pcm.data(), pcm.size(), data.data(), data.size());
+  ++n_cases;
+}
+static void try_out(const Bytes& b) {
+  dsm_out_msg m;
+  char text[32];
+  float prs[4];
+  (void)dsm_outmsg_decode(b.data(), b.size(), &m, text, sizeof text, prs, 4);
+  ++n_cases;
+}
+
+static Bytes enc_in(const dsm_in_msg& m) {
+  Bytes b((size_t)dsm_inmsg_encode(&m, nullptr, 0));
+  REQUIRE(dsm_inmsg_encode(&m, b.data(), b.size()) == (int)b.size());
+  return b;
+}
+static Bytes enc_out(const dsm_out_msg& m) {
+  Bytes b((size_t)dsm_outmsg_encode(&m, nullptr, 0));
+  REQUIRE(dsm_outmsg_encode(&m, b.data(), b.size()) == (int)b.size());
+  return b;
+}
+
+static void fuzz_msgpack() {
+  // the ADVICE r01 reproducer: an unknown key holding 3 M nested one-element arrays must be refused, not recursed into
+  for (uint8_t nest : {(uint8_t)0x91, (uint8_t)0x81}) {
+    Bytes b = {0x82, 0xa4, 't', 'y', 'p', 'e', 0xa4, 'P', 'i', 'n', 'g', 0xa1, 'x'};
+    for (int i = 0; i < 3000000; ++i) { b.push_back(nest); if (nest == 0x81) b.push_back(0x00); }
+    b.push_back(0x00);
+    dsm_in_msg m;
+    REQUIRE(dsm_inmsg_decode(b.data(), b.size(), &m, nullptr, 0, nullptr, 0) == DSM_ERR_IO);
+    try_out(b);
+  }
+  {  // nesting below the limit inside an unknown field is skipped like serde does
+    Bytes b = {0x82, 0xa4, 't', 'y', 'p', 'e', 0xa4, 'P', 'i', 'n', 'g', 0xa1, 'x'};
+    for (int i = 0; i < 500; ++i) b.push_back(0x91);
+    b.push_back(0xc0);
+    dsm_in_msg m;
+    REQUIRE(dsm_inmsg_decode(b.data(), b.size(), &m, nullptr, 0, nullptr, 0) == 0 && m.kind == DSM_IN_PING);
+  }
+  // declared lengths far beyond the message (array32 / map32 / str32 / bin32 / ext32) in every field position
+  for (uint8_t t : {(uint8_t)0xdd, (uint8_t)0xdf, (uint8_t)0xdb, (uint8_t)0xc6, (uint8_t)0xc9, (uint8_t)0xdc, (uint8_t)0xde}) {
+    for (const char* key : {"pcm", "data", "id", "type", "zzz"}) {
+      Bytes b = {0x82, 0xa4, 't', 'y', 'p', 'e', 0xa5, 'A', 'u', 'd', 'i', 'o'};
+      b.push_back((uint8_t)(0xa0 | strlen(key)));
+      b.insert(b.end(), key, key + strlen(key));
+      b.push_back(t);
+      for (int i = 0; i < 4; ++i) b.push_back(0xff);
+      b.push_back(0x01);
+      try_in(b);
+      try_out(b);
+    }
+  }
+  {  // oversized message: refused before any parsing
+    Bytes b(((size_t)64 << 20) + 16, 0xc0);
+    b[0] = 0x81;
+    dsm_in_msg m;
+    REQUIRE(dsm_inmsg_decode(b.data(), b.size(), &m, nullptr, 0, nullptr, 0) == DSM_ERR_IO);
+    ++n_cases;
+  }
+  // seeds: every message kind, then every prefix (truncation) and 4000 random mutations of each
+  std::vector<Bytes> seeds;
+  std::vector<float> pcm(300);
+  for (size_t i = 0; i < pcm.size(); ++i) pcm[i] = (float)std::sin(0.1 * (double)i);
+  std::vector<uint8_t> ogg(70, 0x4f);
+  for (int kind = 0; kind <= DSM_IN_PING; ++kind) {
+    dsm_in_msg m{};
+    m.kind = kind; m.id = -77777; m.pcm = pcm.data(); m.n_pcm = pcm.size(); m.data = ogg.data(); m.n_data = ogg.size();
+    seeds.push_back(enc_in(m));
+  }
+  float prs[4] = {0.1f, 0.2f, 0.3f, 0.4f};
+  for (int kind = 0; kind <= DSM_OUT_READY; ++kind) {
+    dsm_out_msg m{};
+    m.kind = kind; m.text = "h\xc3\xa9llo"; m.time = 1.25; m.id = 1ll << 40; m.step_idx = 70000; m.prs = prs; m.n_prs = 4; m.buffered_pcm = 1920;
+    seeds.push_back(enc_out(m));
+  }
+  for (const Bytes& s : seeds) {
+    for (size_t cut = 0; cut <= s.size(); ++cut) { Bytes b(s.begin(), s.begin() + (long)cut); try_in(b); try_out(b); }
+    for (int it = 0; it < 4000; ++it) {
+      Bytes b = s;
+      const int edits = 1 + (int)(rnd() % 4);
+      for (int e = 0; e < edits; ++e) {
+        const uint32_t op = rnd() % 4;
+        if (b.empty()) break;
+        const size_t at = rnd() % b.size();
+        if (op == 0) b[at] = (uint8_t)rnd();
+        else if (op == 1) b[at] ^= (uint8_t)(1u << (rnd() % 8));
+        else if (op == 2) b.erase(b.begin() + (long)at);
+        else b.insert(b.begin() + (long)at, (uint8_t)rnd());
+      }
+      try_in(b);
+      try_out(b);
+    }
+  }
+}
+
+// ---- the worker on a scripted backend: long words (token buffer growth), malformed backend messages ----
+struct FakeBackend {
+  int B = 3, steps = 0, word_len = 0, bad_slot = 0;
+  std::vector<dsm_asr_msg> msgs;
+  std::vector<uint32_t> toks;
+};
+static int fb_encode(void*, const float*, const uint8_t*) { return 0; }
+static int fb_reset(void*, int) { return 0; }
+static int fb_step(void* self, const uint8_t* mask, uint32_t* text, float* prs) {
+  FakeBackend* f = (FakeBackend*)self;
+  f->steps += 1;
+  f->msgs.clear();
+  f->toks.clear();
+  dsm_asr_msg st{};
+  st.kind = DSM_MSG_STEP; st.step_idx = f->steps;
+  f->msgs.push_back(st);
+  for (int b = 0; b < f->B; ++b) {
+    text[b] = (uint32_t)b;
+    if (prs) prs[b] = 0.5f;
+    if (!mask[b]) continue;
+    dsm_asr_msg w{};
+    w.kind = DSM_MSG_WORD; w.batch_idx = f->bad_slot ? f->B + 5 : b; w.time = 0.08 * f->steps;
+    w.tokens_offset = (int)f->toks.size(); w.n_tokens = f->word_len;
+    for (int i = 0; i < f->word_len; ++i) f->toks.push_back((uint32_t)(i + b));
+    f->msgs.push_back(w);
+    dsm_asr_msg e{};
+    e.kind = DSM_MSG_END_WORD; e.batch_idx = b; e.time = 0.08 * f->steps;
+    f->msgs.push_back(e);
+  }
+  return 0;
+}
+static int fb_poll(void* self, dsm_asr_msg* msgs, int cap, uint32_t* toks, int tcap) {
+  FakeBackend* f = (FakeBackend*)self;
+  int n = (int)f->msgs.size() < cap ? (int)f->msgs.size() : cap;
+  for (int i = 0; i < n; ++i) msgs[i] = f->msgs[i];
+  int nt = (int)f->toks.size() < tcap ? (int)f->toks.size() : tcap;
+  if (nt > 0) memcpy(toks, f->toks.data(), sizeof(uint32_t) * (size_t)nt);
+  return n;
+}
+
+static void fuzz_worker() {
+  FakeBackend fb;
+  dsm_worker_backend be{};
+  be.self = &fb; be.batch_size = fb.B; be.asr_delay_in_tokens = 2; be.extra_heads_num = 1;
+  be.encode_step = fb_encode; be.reset_slot = fb_reset; be.step_tokens = fb_step; be.poll_msgs = fb_poll;
+  dsm_worker* w = nullptr;
+  REQUIRE(dsm_worker_create_with_backend(&be, &w) == 0);
+  uint64_t cid;
+  int slots[3];
+  for (int i = 0; i < 3; ++i) REQUIRE((slots[i] = dsm_worker_open(w, &cid)) >= 0);
+  REQUIRE(dsm_worker_open(w, &cid) == DSM_ERR_STATE);  // at capacity
+  std::vector<float> pcm(DSM_FRAME_SIZE * 2 + 17, 0.25f);
+  auto audio = [&](int slot) {
+    dsm_in_msg m{};
+    m.kind = DSM_IN_AUDIO; m.pcm = pcm.data(); m.n_pcm = pcm.size();
+    Bytes b = enc_in(m);
+    REQUIRE(dsm_worker_send(w, slot, b.data(), b.size()) == 0);
+  };
+  // a word far longer than the first token buffer (8*B + 64): must arrive whole
+  fb.word_len = 5000;
+  for (int i = 0; i < 3; ++i) audio(slots[i]);
+  REQUIRE(dsm_worker_step(w) == 1);
+  Bytes buf(1 << 20);
+  size_t len = 0;
+  int words = 0;
+  for (int i = 0; i < 3; ++i)
+    while (dsm_worker_recv(w, slots[i], buf.data(), buf.size(), &len) == 1) {
+      dsm_out_msg om;
+      std::vector<char> text(200000);
+      float prs[8];
+      REQUIRE(dsm_outmsg_decode(buf.data(), len, &om, text.data(), text.size(), prs, 8) == 0);
+      if (om.kind == DSM_OUT_WORD) {
+        ++words;
+        size_t spaces = 0;
+        for (const char* p = om.text; *p; ++p) spaces += *p == ' ';
+        REQUIRE(spaces == 4999);  // all 5000 piece ids are there
+      }
+    }
+  REQUIRE(words == 3);
+  // random garbage on the sockets between steps; closing and reopening slots
+  fb.word_len = 3;
+  for (int it = 0; it < 3000; ++it) {
+    const int slot = (int)(rnd() % 3);
+    Bytes b(rnd() % 40);
+    for (auto& v : b) v = (uint8_t)rnd();
+    (void)dsm_worker_send(w, slot, b.data(), b.size());
+    if (it % 7 == 0) audio(slot);
+    if (it % 5 == 0) (void)dsm_worker_step(w);
+    if (it % 211 == 0) { (void)dsm_worker_close(w, slot); (void)dsm_worker_step(w); (void)dsm_worker_open(w, &cid); }
+    while (dsm_worker_recv(w, slot, buf.data(), buf.size(), &len) == 1) {}
+    ++n_cases;
+  }
+  // a backend that names a slot outside the batch is an error, not an out-of-bounds access
+  fb.bad_slot = 1;
+  for (int i = 0; i < 3; ++i) audio(i);
+  int rc = 0;
+  for (int i = 0; i < 4 && rc >= 0; ++i) rc = dsm_worker_step(w);
+  REQUIRE(rc == DSM_ERR_STATE);
+  dsm_worker_destroy(w);
+}
+
+// ---- RIFF/WAVE ----
+static Bytes make_wav(uint16_t fmt, uint16_t ch, uint32_t rate, uint16_t bits, size_t frames, bool extensible) {
+  Bytes b;
+  auto p16 = [&](uint32_t v) { b.push_back((uint8_t)v); b.push_back((uint8_t)(v >> 8)); };
+  auto p32 = [&](uint32_t v) { p16(v & 0xffff); p16(v >> 16); };
+  auto tag = [&](const char* t) { b.insert(b.end(), t, t + 4); };
+  const size_t data = frames * ch * (bits / 8);
+  tag("RIFF"); p32((uint32_t)(36 + data)); tag("WAVE");
+  tag("fmt "); p32(extensible ? 40 : 16);
+  p16(extensible ? 0xFFFE : fmt); p16(ch); p32(rate); p32(rate * ch * bits / 8); p16((uint16_t)(ch * bits / 8)); p16(bits);
+  if (extensible) { p16(22); p16(bits); p32(3); p16(fmt); for (int i = 0; i < 14; ++i) b.push_back((uint8_t)i); }
+  tag("LIST"); p32(3); b.push_back('a'); b.push_back('b'); b.push_back('c'); b.push_back(0);  // odd-sized chunk + pad
+  tag("data"); p32((uint32_t)data);
+  for (size_t i = 0; i < data; ++i) b.push_back((uint8_t)rnd());
+  return b;
+}
+static void try_wav(const Bytes& b) {
+  float* pcm = nullptr;
+  size_t n = 0;
+  int rate = 0;
+  if (dsm_wav_decode(b.data(), b.size(), &pcm, &n, &rate) == 0) {
+    volatile float acc = 0;
+    for (size_t i = 0; i < n; ++i) acc = acc + pcm[i];  // touch every sample the decoder claims to have written
+    dsm_free(pcm);
+  }
+  ++n_cases;
+}
+static void fuzz_wav() {
+  std::vector<Bytes> seeds;
+  for (uint16_t bits : {(uint16_t)8, (uint16_t)16, (uint16_t)24, (uint16_t)32}) seeds.push_back(make_wav(1, 2, 48000, bits, 50, false));
+  seeds.push_back(make_wav(3, 1, 24000, 32, 40, false));
+  seeds.push_back(make_wav(1, 2, 44100, 16, 40, true));
+  seeds.push_back(make_wav(1, 0, 44100, 16, 0, false));       // zero channels
+  seeds.push_back(make_wav(1, 65535, 44100, 32, 1, false));   // huge frame size
+  seeds.push_back(make_wav(1, 1, 44100, 0, 0, false));        // zero bits
+  for (Bytes& s : seeds) {
+    try_wav(s);
+    for (size_t cut = 0; cut <= s.size(); cut += cut < 256 ? 1 : 1 + rnd() % (s.size() / 64 + 1))  // every header prefix, a sample of body cuts
+      try_wav(Bytes(s.begin(), s.begin() + (long)cut));
+    for (int it = 0; it < (s.size() < 4096 ? 3000 : 300); ++it) {
+      Bytes b = s;
+      const int edits = 1 + (int)(rnd() % 3);
+      for (int e = 0; e < edits; ++e) b[rnd() % b.size()] = (uint8_t)rnd();
+      if (it % 3 == 0) b.resize(rnd() % (b.size() + 1));
+      try_wav(b);
+    }
+    Bytes big = s;  // data chunk that claims 4 GiB ("streamed" files carry 0xFFFFFFFF)
+    for (size_t o = 12; o + 8 <= big.size(); ++o)
+      if (!memcmp(&big[o], "data", 4)) { memset(&big[o + 4], 0xff, 4); break; }
+    try_wav(big);
+  }
+  dsm_resampler* r = dsm_linear_resampler_new(44100, 24000);
+  std::vector<float> in(1000, 0.5f), out(8);
+  for (int i = 0; i < 50; ++i) (void)dsm_linear_resampler_process(r, in.data(), rnd() % in.size(), out.data(), out.size());  // out_cap smaller than produced
+  dsm_linear_resampler_free(r);
+  REQUIRE(dsm_linear_resampler_new(0, 24000) == nullptr);
+}
+
+// ---- safetensors ----
+static void try_st(const std::string& dir, const Bytes& b) {
+  const std::string path = dir + "/fuzz.safetensors";
+  FILE* f = fopen(path.c_str(), "wb");
+  REQUIRE(f);
+  if (!b.empty()) REQUIRE(fwrite(b.data(), 1, b.size(), f) == b.size());
+  fclose(f);
+  char err[256];
+  dsm_st_file* st = dsm_st_open(path.c_str(), err, sizeof err);
+  if (st) {
+    for (int i = 0; i < st->n_tensors; ++i) {
+      const int64_t n = dsm_st_numel(&st->tensors[i]);
+      if (n >= 0 && n < (1 << 20)) {
+        std::vector<float> out((size_t)n + 1);
+        (void)dsm_st_read_f32(st, st->tensors[i].name, n, out.data(), err, sizeof err);
+        (void)dsm_st_read_f32(st, st->tensors[i].name, n + 1, out.data(), err, sizeof err);
+      }
+    }
+    (void)dsm_st_find(st, "nope");
+    dsm_st_close(st);
+  }
+  ++n_cases;
+}
+static Bytes st_file(const std::string& header, size_t data_bytes) {
+  Bytes b(8);
+  uint64_t n = header.size();
+  memcpy(b.data(), &n, 8);
+  b.insert(b.end(), header.begin(), header.end());
+  for (size_t i = 0; i < data_bytes; ++i) b.push_back((uint8_t)rnd());
+  return b;
+}
+static void fuzz_safetensors(const std::string& dir) {
+  const std::string good =
+      "{\"__metadata__\":{\"format\":\"pt\",\"nested\":{\"a\":[1,2,{\"b\":\"}\"}]}},"
+      "\"w\":{\"dtype\":\"F32\",\"shape\":[2,3],\"data_offsets\":[0,24]},"
+      "\"b\":{\"dtype\":\"BF16\",\"shape\":[4],\"data_offsets\":[24,32]},"
+      "\"h\":{\"dtype\":\"F16\",\"shape\":[2],\"data_offsets\":[32,36]},"
+      "\"s\":{\"dtype\":\"F32\",\"shape\":[],\"data_offsets\":[36,40]}}";
+  {
+    Bytes b = st_file(good, 40);
+    try_st(dir, b);
+    char err[256];
+    const std::string path = dir + "/fuzz.safetensors";
+    dsm_st_file* st = dsm_st_open(path.c_str(), err, sizeof err);
+    REQUIRE(st && st->n_tensors == 4);
+    float w[6];
+    REQUIRE(dsm_st_read_f32(st, "w", 6, w, err, sizeof err) == 0);
+    REQUIRE(dsm_st_read_f32(st, "w", 5, w, err, sizeof err) == -1);
+    REQUIRE(dsm_st_read_f32(st, "h", 2, w, err, sizeof err) == -1);  // F16 unsupported
+    dsm_st_close(st);
+    for (size_t cut = 0; cut <= b.size(); ++cut) try_st(dir, Bytes(b.begin(), b.begin() + (long)cut));
+    for (int it = 0; it < 1500; ++it) {
+      Bytes m = b;
+      const int edits = 1 + (int)(rnd() % 3);
+      for (int e = 0; e < edits; ++e) m[rnd() % m.size()] = (uint8_t)(rnd() % 3 ? rnd() : "{}[]\":,0123456789\\"[rnd() % 19]);
+      try_st(dir, m);
+    }
+  }
+  const char* hostile[] = {
+      "{\"w\":{\"dtype\":\"F32\",\"shape\":[2,3],\"data_offsets\":[0,99999999999]}}",
+      "{\"w\":{\"dtype\":\"F32\",\"shape\":[2,3],\"data_offsets\":[30,24]}}",
+      "{\"w\":{\"dtype\":\"F32\",\"shape\":[99999999999999999999999999999999],\"data_offsets\":[0,24]}}",
+      "{\"w\":{\"dtype\":\"F32\",\"shape\":[4294967296,4294967296,4294967296],\"data_offsets\":[0,24]}}",
+      "{\"w\":{\"dtype\":\"F32\",\"shape\":[1,2,3,4,5,6,7,8,9,10,11,12],\"data_offsets\":[0,24]}}",
+      "{\"w\":{\"dtype\":\"F32\",\"shape\":[6],\"data_offsets\":[0,20]}}",
+      "{\"w\":{\"dtype\":\"F32\",\"shape\":[-2,-3],\"data_offsets\":[0,24]}}",
+      "{\"w\":{\"dtype\":\"F32\",\"shape\":[2,3]}}",
+      "{\"unterminated",
+      "{\"w\":{\"dtype\":\"F32\",\"shape\":[2,3],\"data_offsets\":[0,24]",
+      "{\"__metadata__\":{{{{{{{{{{{{{{{{{{{{{{{{{{{{{{{{",
+      "{\"w\":\"not an object\"}",
+      "[1,2,3]",
+      "",
+      "{\"a\\\"b\\\\\":{\"dtype\":\"F32\",\"shape\":[1],\"data_offsets\":[0,4]}}",
+  };
+  for (const char* h : hostile) try_st(dir, st_file(h, 24));
+  {  // header length field beyond the file / near 2^64
+    Bytes b = st_file(good, 40);
+    for (uint64_t v : std::vector<uint64_t>{(uint64_t)b.size(), (uint64_t)b.size() - 7, ~(uint64_t)0, ~(uint64_t)0 - 7, (uint64_t)1 << 63}) {
+      memcpy(b.data(), &v, 8);
+      try_st(dir, b);
+    }
+  }
+  {  // many tensors: the table grows past its first allocation
+    std::string h = "{";
+    for (int i = 0; i < 700; ++i) {
+      char e[128];
+      snprintf(e, sizeof e, "%s\"t%d\":{\"dtype\":\"F32\",\"shape\":[1],\"data_offsets\":[%d,%d]}", i ? "," : "", i, 4 * i, 4 * i + 4);
+      h += e;
+    }
+    h += "}";
+    try_st(dir, st_file(h, 2800));
+  }
+}
+
+#include <chrono>
+int main(int argc, char** argv) {
+  const std::string dir = argc > 1 ? argv[1] : "/tmp";
+  auto t0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "  %-12s %6.1f s, %ld cases so far\n", what, std::chrono::duration<double>(t1 - t0).count(), n_cases);
+    t0 = t1;
+  };
+  fuzz_msgpack(); lap("msgpack");
+  fuzz_worker(); lap("worker");
+  fuzz_wav(); lap("wav");
+  fuzz_safetensors(dir); lap("safetensors");
+  printf("host_fuzz ok: %ld cases, no sanitizer report\n", n_cases);
+  return 0;
+}

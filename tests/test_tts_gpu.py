@@ -83,6 +83,40 @@ def test_tts_errors(gpu, dsm, lib, tts):
         dsm.TtsEngine(cfg, 1, path + ".missing")
 
 
+def test_tts_stepping_past_the_limit_is_refused_without_side_effects(gpu, dsm, lib, orc, tts):
+    """A slot that reached n_steps (the step that returned "max step-idx reached") must not be stepped again: the
+    reference would index text_tokens[n_steps] (a panic); the engine refuses the step and changes nothing, for any number
+    of further calls, while the other slot of the batch keeps generating once the full slot is masked out or reset."""
+    cfg, path = tts
+    small = dsm.TtsConfig.from_buffer_copy(cfg)
+    small.max_steps = 4
+    n = small.max_steps + small.acoustic_delay
+    eng, ora = dsm.TtsEngine(small, 2, path), orc.OracleTts(small, 2, path)
+    for s in range(n - 1):  # slot 1 starts one step later than slot 0
+        args = ([1, 2], [9, 11], [1, 1 if s else 0])
+        te, ae = eng.step(*args)
+        to, ao = ora.step(*args)
+        assert np.array_equal(te[:1], to[:1]) and np.array_equal(ae[:1], ao[:1])
+    with pytest.raises(dsm.DsmError, match="max step-idx"):
+        eng.step([1, 2], [9, 11], [1, 1])  # slot 0 reaches the limit; slot 1 was advanced too
+    with pytest.raises(RuntimeError):
+        ora.step([1, 2], [9, 11], [1, 1])
+    assert eng.step_idx(0) == n == ora.step_idx(0) and eng.step_idx(1) == n - 1 == ora.step_idx(1)
+    tables = [eng.audio_tokens(b, i).copy() for b in range(2) for i in range(n)]
+    for _ in range(2):  # twice past the limit: refused, no state change (this used to write past the vectors)
+        with pytest.raises(dsm.DsmError, match="max step-idx"):
+            eng.step([1, 2], [9, 11], [1, 1])
+        with pytest.raises(RuntimeError):
+            ora.step([1, 2], [9, 11], [1, 1])
+        assert eng.step_idx(0) == n and eng.step_idx(1) == n - 1 and ora.step_idx(1) == n - 1
+        assert all(np.array_equal(a, b) for a, b in zip(tables, [eng.audio_tokens(b, i) for b in range(2) for i in range(n)]))
+    eng.reset_batch_idx(0); ora.reset_batch_idx(0)  # the full slot is recycled, the batch goes on
+    te, ae = eng.step([1, 2], [9, 11], [1, 0])
+    to, ao = ora.step([1, 2], [9, 11], [1, 0])
+    assert np.array_equal(te[:1], to[:1]) and np.array_equal(ae[:1], ao[:1]) and eng.step_idx(0) == 1
+    eng.close(); ora.close()
+
+
 def test_tts_engine_creation_is_race_free(gpu, dsm, lib, orc, tts):
     """Regression for a load-time race: the low-rank depformer tables are folded by a GEMM on the engine's
     (non-blocking) stream right after their operands are uploaded on the null stream; without an explicit wait the fold

@@ -94,6 +94,13 @@ def test_max_step_idx_is_an_error(dsm, orc, tts):
         o.step([1], [9], [1])
     with pytest.raises(RuntimeError):  # "max step-idx reached" (:238-240)
         o.step([1], [9], [1])
+    for _ in range(2):  # a slot at the limit is refused, not stepped (the reference would panic on text_tokens[n])
+        with pytest.raises(RuntimeError):
+            o.step([1], [9], [1])
+        assert o.step_idx(0) == n
+    o.reset_batch_idx(0)
+    o.step([1], [9], [1])
+    assert o.step_idx(0) == 1
     o.close()
 
 
