@@ -8,7 +8,9 @@ KV, batch 64 per GPU (BASELINE.json configs[1]); synthetic Philox weights and PC
 offline).  Before the warmup an UNTIMED fill of `context` steps brings every slot's ring cache to
 steady state, so each timed step streams the whole 750-frame KV cache.
 
-  python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+      N > 1 without a launcher: spawns N ranks itself (python -m torch.distributed.run ... bench.py, as child
+      processes, before this process imports torch); under a launcher (WORLD_SIZE set) it is one of the ranks.
 
 Prints ONE JSON line on rank 0.  Multi-GPU: independent stream batches per GPU (weak scaling), no
 per-step collective; the shared weights are fanned out once at load with an RCCL broadcast.
@@ -41,6 +43,10 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true", help="single-stream step_pcm instead of the encoder/model stream pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--capacity-legs", default="400,2048",
+                    help="comma-separated larger batches timed after the headline run (N = 1 only; '' to skip)")
+    ap.add_argument("--spawn-check", action="store_true",
+                    help="CPU rehearsal of the multi-rank control path (gloo): no engine, no GPU")
     ap.add_argument("--weights-dir", default=os.environ.get("DSM_WEIGHTS_DIR", "/tmp/dsm_weights"))
     return ap.parse_args()
 
@@ -150,23 +156,112 @@ def bench_tts(args, world, rank, local_rank):
     eng.close()
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N fresh ranks (one per GPU) with torch.distributed.run and
+    let rank 0's JSON line through.  This parent has not imported torch nor touched the GPU, and it never execs: the
+    ranks are child processes and their exit code becomes ours."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
+def spawn_check(args, world, rank):
+    """CPU rehearsal of the N > 1 control path (tests/test_bench_spawn_cpu.py): gloo process group, the load-time
+    broadcast of a byte blob, barrier-bracketed timing with a MAX over ranks, one JSON line on rank 0.  No engine."""
+    import torch
+    import torch.distributed as dist
+    from dsm_amd import sharding
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo")
+    blob = torch.arange(1 << 16, dtype=torch.int64).to(torch.uint8) if rank == 0 else torch.zeros(1 << 16, dtype=torch.uint8)
+    sharding.broadcast_tensor_(blob, 0, dist, chunk_bytes=10000)
+    ok = bool((blob == torch.arange(1 << 16, dtype=torch.int64).to(torch.uint8)).all())
+    dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    flags = torch.tensor([1 if ok else 0], dtype=torch.int64)
+    dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        print(json.dumps({"metric": "spawn-check", "n_gpus": world, "value": float(dt.item()), "unit": "s", "steps": args.steps,
+                          "warmup": args.warmup, "broadcast_ok": bool(flags.item()), "backend": "gloo"}))
+    dist.destroy_process_group()
+
+
+def timed_steps(step, n, barrier):
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    barrier()
+    return time.perf_counter() - t0
+
+
+def capacity_leg(dsm_amd, synth, cfg, B, arena, dev, local_rank, steps, torch):
+    """One extra engine of B slots attached to the already loaded weight arena, ring positions jumped to steady state
+    (cache content is whatever HBM holds: same traffic, same arithmetic), a short warmup and `steps` timed frames of the
+    two-stream pipeline.  Returns ms per step."""
+    ptr, nbytes, manifest = arena
+    eng = dsm_amd.AsrEngine(cfg, B, device_id=local_rank, arena=(ptr, nbytes, manifest))
+    try:
+        n_pcm = 4
+        pcm = torch.from_numpy(synth.synth_pcm(64, n_pcm, seed=77)).to(dev).repeat(1, (B + 63) // 64, 1)[:, :B].contiguous()
+        mask = torch.ones(B, dtype=torch.uint8, device=dev)
+        text = torch.zeros(B, dtype=torch.int32, device=dev)
+        prs = torch.zeros(max(cfg.extra_heads_num, 1) * B, dtype=torch.float32, device=dev)
+        codes = torch.zeros(B * cfg.audio_codebooks, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        eng.debug_set_positions(4 * cfg.lm.context, 4 * cfg.mimi.transformer.context)
+        it = [0]
+
+        def step():
+            eng.encode_step_dev(pcm[it[0] % n_pcm].data_ptr(), mask.data_ptr(), codes.data_ptr())
+            eng.step_tokens_dev(None, mask.data_ptr(), text.data_ptr(), prs.data_ptr())
+            it[0] += 1
+
+        for _ in range(3):
+            step()
+        dt = timed_steps(step, steps, torch.cuda.synchronize)
+        return dt / steps * 1000.0
+    finally:
+        eng.close()
+
+
 def main():
     args = parse()
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None:
+        sys.exit(spawn_ranks(args))  # before torch is imported or the GPU touched in this process
+    world = int(world_env or "1")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world_env is not None and args.gpus != world and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks; reporting n_gpus = {world}", file=sys.stderr)
+    if args.spawn_check:
+        return spawn_check(args, world, rank)
     import torch
     import torch.distributed as dist
     import dsm_amd
-    from dsm_amd import synth
+    from dsm_amd import synth, sharding
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
     if args.workload == "tts":
         return bench_tts(args, world, rank, local_rank)
 
@@ -174,31 +269,16 @@ def main():
            "tiny": dsm_amd.config_tiny}[args.config]()
     B = args.batch
     tag = args.config
-    # rank 0 writes the synthetic checkpoint; the other ranks get the bytes over RCCL (the only collective)
+    # rank 0 writes + loads the synthetic checkpoint; the other ranks receive the packed device weight arena over RCCL
+    # (the only collective of the whole path) and attach to it
+    lm_path = mimi_path = None
     if rank == 0:
         lm_path, mimi_path = synth.make_synth_weights(cfg, args.weights_dir, tag=tag)
-    bcast_ms = None
+    fan = None
     if world > 1:
-        from dsm_amd import sharding
-        paths = []
-        for which in ("lm", "mimi"):
-            raw = np.fromfile(lm_path if which == "lm" else mimi_path, dtype=np.uint8) if rank == 0 else np.zeros(0, np.uint8)
-            torch.cuda.synchronize()
-            t0 = time.time()
-            got = sharding.broadcast_bytes(raw, 0, dist, device=dev)  # RCCL over xGMI: the only collective
-            bcast_ms = (bcast_ms or 0.0) + (time.time() - t0) * 1000
-            if rank != 0:
-                p = os.path.join(args.weights_dir, f"{tag}.rank{rank}.{which}.safetensors")
-                os.makedirs(args.weights_dir, exist_ok=True)
-                got.tofile(p)
-                paths.append(p)
-            del got
-        if rank != 0:
-            lm_path, mimi_path = paths
-    eng = dsm_amd.AsrEngine(cfg, B, lm_path, mimi_path, device_id=local_rank)
-    if world > 1 and rank != 0:
-        for p in (lm_path, mimi_path):
-            os.remove(p)
+        eng, fan = sharding.fan_out_engine(dsm_amd, cfg, B, lm_path, mimi_path, dist, dev, src=0)
+    else:
+        eng = dsm_amd.AsrEngine(cfg, B, lm_path, mimi_path, device_id=local_rank)
 
     if args.workload == "mimi-decode":
         return bench_decode(args, eng, cfg, B, dev, world, rank, dist, torch)
@@ -212,8 +292,11 @@ def main():
     prs = torch.zeros(max(cfg.extra_heads_num, 1) * B, dtype=torch.float32, device=dev)
     codes = torch.zeros(B * cfg.audio_codebooks, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()  # uploads above ran on torch's stream; the engine's streams are not ordered against it
+    it = [0]
 
-    def step(i):
+    def step():
+        i = it[0]
+        it[0] += 1
         if args.no_overlap:  # everything on one stream (asr::State::step_pcm)
             eng.step_pcm_dev(pcm[i % n_pcm].data_ptr(), mask.data_ptr(), codes.data_ptr(), text.data_ptr(), prs.data_ptr())
         else:
@@ -227,39 +310,36 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    it = 0
     if args.fast_fill:
         eng.debug_set_positions(4 * ctx, 4 * cfg.mimi.transformer.context)
     elif not args.no_fill:
         for _ in range(ctx):
-            step(it)
-            it += 1
+            step()
         torch.cuda.synchronize()
     for _ in range(args.warmup):
-        step(it)
-        it += 1
-    # ---- timed region: exactly K steps, dominant kernel bracketed by HIP events on its own stream ----
-    eng.prof_enable(["attn_lm"])
-    eng.prof_read()
-    eng.prof_read_device()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(it)
-        it += 1
-    barrier()
-    dt = time.perf_counter() - t0
-    prof = eng.prof_read()
-    prof_dev = eng.prof_read_device()
+        step()
+    # ---- timed region: exactly K steps, no instrumentation of any kind inside it ----
     eng.prof_enable([])
+    dt = timed_steps(step, args.steps, barrier)
     dt_t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
     dt = float(dt_t.item())
     ms_per_step = dt / args.steps * 1000.0
 
-    # one extra single-stream pass (not part of `value`): per-class device time of a step, and the dominant kernel
-    # timed without a concurrent stream competing for HBM
+    # ---- separate pass (not part of `value`): the dominant kernel bracketed live, i.e. with the other streams running
+    # beside it — HIP events on the stream it is launched on + the in-kernel device-clock bracket ----
+    n_prof = min(args.steps, 20)
+    eng.prof_enable(["attn_lm"])
+    eng.prof_read()
+    eng.prof_read_device()
+    dt_prof = timed_steps(step, n_prof, torch.cuda.synchronize)
+    prof = eng.prof_read()
+    prof_dev = eng.prof_read_device()
+    eng.prof_enable([])
+
+    # one extra single-stream pass: per-class device time of a step, and the dominant kernel timed without a concurrent
+    # stream competing for HBM
     overlap = not args.no_overlap
     args.no_overlap = True
     torch.cuda.synchronize()
@@ -268,8 +348,7 @@ def main():
     eng.prof_read()
     eng.prof_read_device()
     for _ in range(5):
-        step(it)
-        it += 1
+        step()
     iso = eng.prof_read()
     iso_dev = eng.prof_read_device()
     breakdown = {k: round(v[0] / 5.0, 1) for k, v in iso.items()}
@@ -278,10 +357,23 @@ def main():
     args.no_overlap = not overlap
     groups = eng.stream_groups()
 
+    # ---- capacity legs (N = 1 only): larger batches attached to the same weight arena.  BASELINE.json's north star is
+    # ">= 400 concurrent real-time streams per MI355X at RTF > 1" ----
+    legs = {}
+    if world == 1 and args.capacity_legs and args.config != "tiny":
+        arena = eng.weight_arena()
+        for Bl in [int(x) for x in args.capacity_legs.split(",") if x]:
+            try:
+                ms = capacity_leg(dsm_amd, synth, cfg, Bl, arena, dev, local_rank, 20 if Bl <= 512 else 8, torch)
+                legs[Bl] = {"ms_per_step": ms, "rtf": 80.0 / ms, "x_realtime": Bl * 80.0 / ms}
+            except Exception as ex:  # e.g. another tenant's memory on the card: report, do not lose the headline line
+                legs[Bl] = {"error": str(ex)[:200]}
+            torch.cuda.empty_cache()
+
     if rank == 0:
         H, hd, L = cfg.lm.num_heads, cfg.lm.d_model // cfg.lm.num_heads, cfg.lm.num_layers
         kv_b = 2 if cfg.kv_bf16 else 4
-        fill = ctx if not args.no_fill else min(it, ctx)
+        fill = ctx if not args.no_fill else min(it[0], ctx)
         # algorithmic bytes of the attention launches of ONE layer: K and V of every (slot, head) once + q in + out.
         # The LM step runs the batch as len(groups) stream groups, each with its own attention launch per layer, so a
         # launch covers B / len(groups) slots on average and `achieved` is bytes of all timed launches / their time.
@@ -294,15 +386,19 @@ def main():
         attn_bytes = attn_bytes_layer / len(groups)
         # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (bench.py cannot run under --pmc and
         # time itself): 2 x FETCH_SIZE (gfx950 counts 64 B per 128-B request) + WRITE_SIZE, per dispatch
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_hbm_traffic.json")))
-            for k in pmc["kernels"]:
-                if ("attn_kernel<unsigned short, %d, 1>" % hd in k["kernel"] and args.config == "stt-1b-en_fr"
-                        and B == 64 and k.get("slots_per_dispatch", 64) * len(groups) == B):
-                    traffic = (2 * k["FETCH_SIZE_KB_per_dispatch"] + k["WRITE_SIZE_KB_per_dispatch"]) * 1024
-        except Exception:
-            pass
+        traffic, traffic_src = None, None
+        for rnd in ("r02", "r01"):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", rnd, "pmc_hbm_traffic.json")))
+                for k in pmc["kernels"]:
+                    if ("attn_kernel<unsigned short, %d, 1>" % hd in k["kernel"] and args.config == "stt-1b-en_fr"
+                            and B == 64 and k.get("slots_per_dispatch", 64) * len(groups) == B):
+                        traffic = (2 * k["FETCH_SIZE_KB_per_dispatch"] + k["WRITE_SIZE_KB_per_dispatch"]) * 1024
+                        traffic_src = f"profiles/{rnd}/pmc_hbm_traffic.json (rocprofv3 --pmc, separate passes; not measured in this run)"
+            except Exception:
+                pass
+            if traffic:
+                break
         m = eng.metrics()
         step_bytes = m.algorithmic_bytes_lm + m.algorithmic_bytes_encode
         # launch duration = in-kernel device-clock bracket (first workgroup in -> last out), the quantity rocprofv3's
@@ -313,6 +409,7 @@ def main():
         ev_us, ev_n = prof["attn_lm"]
         achieved = attn_bytes / (attn_avg_us * 1e-6) / 1e9 if attn_n else 0.0
         iso_avg_us = iso_dev["attn_lm"][0] / max(iso_dev["attn_lm"][1], 1)
+        ok_legs = [b for b, v in legs.items() if "rtf" in v and v["rtf"] >= 1.0]
         out = {
             "metric": "real-time stream throughput, %s @ bs=%d per GPU (Mimi encode + LM decode per 80 ms frame)" % (args.config, B),
             "value": world * B * 0.08 / (ms_per_step / 1000.0),
@@ -327,16 +424,21 @@ def main():
             "rtf": 80.0 / ms_per_step,
             "config": {"workload": "%s batch=%d streaming, ring KV cache full (%d frames), Mimi encode + LM decode HIP path"
                                    % (args.config, B, fill),
-                       "streams_per_gpu": B, "parallelism": "replicas x%d (independent stream batches)" % world,
+                       "streams_per_gpu": B, "parallelism": "replicas x%d (independent stream batches, no per-step collective)" % world,
                        "streams": "single stream" if args.no_overlap else "encoder stream || %d LM group stream(s)" % len(groups),
-                       "weights_broadcast_ms": bcast_ms},
+                       "rccl_ranks": world if world > 1 else None,
+                       "weights_broadcast_ms": fan["broadcast_ms"] if fan else None,
+                       "weights_broadcast_bytes": fan["arena_bytes"] if fan else None,
+                       "weights_broadcast": "packed device weight arena, rank 0 -> all, RCCL over xGMI, once at load" if fan else None,
+                       "timed_region": "instrumentation off; roofline brackets come from a separate %d-step pass (%.3f ms/step with the brackets on)"
+                                       % (n_prof, dt_prof / n_prof * 1000.0)},
             "roofline": {"bound": "hbm", "kernel": "attn_kernel<bf16,hd%d,T1> (LM ring-cache attention%s, %d launches/step: %d layers x %d stream groups of %s slots)"
                                                     % (hd, " with the fused QKV reduce + RoPE + ring scatter prologue" if fused else "", L * len(groups), L, len(groups), "/".join(str(n) for _, n in groups)),
                          "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "algorithmic_bytes_per_launch": attn_bytes, "avg_launch_us": attn_avg_us,
                          "launches_timed": int(attn_n), "timer": "device wall clock inside the kernel (agrees with rocprofv3 --kernel-trace)",
                          "hip_event_bracket_avg_us": ev_us / max(ev_n, 1), "traffic": traffic,
-                         "traffic_source": "profiles/r01/pmc_hbm_traffic.json (rocprofv3 --pmc, separate passes)" if traffic else None,
+                         "traffic_source": traffic_src,
                          "isolated_single_stream": {"avg_launch_us": iso_avg_us,
                                                     "achieved": attn_bytes / (iso_avg_us * 1e-6) / 1e9,
                                                     "frac": attn_bytes / (iso_avg_us * 1e-6) / 1e9 / 8000.0}},
@@ -344,6 +446,12 @@ def main():
             "whole_step": {"algorithmic_bytes": step_bytes, "achieved": step_bytes / (ms_per_step * 1e-3) / 1e9, "unit": "GB/s",
                            "frac_of_hbm_peak": step_bytes / (ms_per_step * 1e-3) / 1e9 / 8000.0},
         }
+        if legs:
+            out["capacity"] = {"legs": {str(b): v for b, v in legs.items()},
+                               "streams_at_rtf_ge_1": max(ok_legs) if ok_legs else None,
+                               "rtf_b400": legs.get(400, {}).get("rtf"),
+                               "note": "same engine build and weight arena, ring positions jumped to steady state, two-stream pipeline, "
+                                       "timed without instrumentation; north star: >= 400 real-time streams per MI355X"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, B, lm_path, mimi_path, args.cpu_steps)
         print(json.dumps(out))

@@ -110,7 +110,7 @@ MSG_STEP, MSG_WORD, MSG_END_WORD = 0, 1, 2
 # Every symbol include/dsm.h declares (the "not gpu" tests check the library exports all of them).
 ABI_SYMBOLS = [
     "dsm_mimi_config_v0_1", "dsm_asr_config_stt_1b_en_fr", "dsm_asr_config_stt_2_6b_en",
-    "dsm_asr_create", "dsm_destroy", "dsm_last_error", "dsm_mimi_encode_step", "dsm_asr_step_tokens",
+    "dsm_asr_create", "dsm_asr_create_from_arena", "dsm_asr_weight_arena", "dsm_destroy", "dsm_last_error", "dsm_mimi_encode_step", "dsm_asr_step_tokens",
     "dsm_asr_step_pcm", "dsm_asr_poll_msgs", "dsm_asr_reset_slot", "dsm_mimi_reset_slot", "dsm_sync",
     "dsm_get_metrics", "dsm_batch_size", "dsm_n_q", "dsm_mimi_encode_step_dev", "dsm_asr_step_tokens_dev",
     "dsm_streams_join", "dsm_debug_read", "dsm_asr_step_pcm_dev", "dsm_prof_enable", "dsm_prof_read",
@@ -146,6 +146,8 @@ def load_library(path=None):
     lib.dsm_asr_config_stt_2_6b_en.argtypes = [C.POINTER(AsrConfig)]
     lib.dsm_asr_create.argtypes = [C.POINTER(AsrConfig), C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.POINTER(vp)]
     lib.dsm_asr_create.restype = C.c_int
+    lib.dsm_asr_create_from_arena.argtypes = [C.POINTER(AsrConfig), C.c_int, C.c_int, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(vp)]
+    lib.dsm_asr_weight_arena.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp), C.POINTER(C.c_size_t)]
     lib.dsm_destroy.argtypes = [vp]
     lib.dsm_destroy.restype = None
     lib.dsm_last_error.argtypes = [vp]
@@ -274,6 +276,27 @@ def config_tiny(kv_bf16=1):
     mt.context, mt.max_period, mt.gating, mt.norm = 10, 10000, 0, 0
     mt.positional_embedding, mt.layer_scale, mt.conv_layout = 1, 1, 1
     m.quantizer_n_q, m.quantizer_bins, m.quantizer_dim, m.downsample_stride = 4, 32, 16, 2
+    return cfg
+
+
+def config_medium(lm_heads=4, lm_head_dim=128, lm_context=300, kv_bf16=1, lm_layers=2, mimi_head_dim=64, mimi_context=250):
+    """Between tiny and real: the LM and Mimi transformers get the REAL head dims (128 / 64) and ring lengths of a few
+    hundred frames, so that the attention kernel's software-pipelined loop runs several iterations per phase (both
+    register sets, the tail clamp after the first iteration, ring wrap) and d_model spans more than one 256-wide
+    K-chunk (split-K slabs, the fused QKV prologue) — while SEANet, the RVQ and the vocabularies stay small enough for
+    the CPU oracle to step a batch in ~10 ms."""
+    cfg = config_tiny(kv_bf16)
+    t = cfg.lm
+    t.d_model, t.num_heads, t.num_layers = lm_heads * lm_head_dim, lm_heads, lm_layers
+    t.dim_feedforward, t.context = 4 * t.d_model, lm_context  # gating hidden = 11 d / 4 (a multiple of 32 for d % 128 == 0)
+    cfg.text_in_vocab_size, cfg.text_out_vocab_size = 257, 256
+    cfg.audio_vocab_size, cfg.audio_codebooks = 65, 8
+    cfg.asr_delay_in_tokens = 3
+    m = cfg.mimi
+    m.dimension, m.n_filters = 2 * mimi_head_dim, 4
+    mt = m.transformer
+    mt.d_model, mt.num_heads, mt.num_layers, mt.dim_feedforward, mt.context = 2 * mimi_head_dim, 2, 2, 256, mimi_context
+    m.quantizer_n_q, m.quantizer_bins, m.quantizer_dim = 8, 64, 32
     return cfg
 
 
@@ -506,18 +529,35 @@ class AsrEngine:
     Method names follow the reference: encode_step (core/mimi.rs:195), step_tokens (core/asr.rs:147),
     step_pcm (core/asr.rs:115), reset_batch_idx (core/asr.rs:257)."""
 
-    def __init__(self, cfg, batch_size, lm_path, mimi_path, device_id=0):
+    def __init__(self, cfg, batch_size, lm_path=None, mimi_path=None, device_id=0, arena=None):
+        """From the two safetensors files, or — `arena=(device_ptr, nbytes, manifest_bytes[, keepalive])` — attached to a
+        packed weight arena another rank broadcast (dsm_asr_create_from_arena); the caller's buffer must outlive the engine
+        (pass it as the optional 4th element and it is kept referenced here)."""
         self.lib = load_library()
         self.cfg = cfg
         self.B = batch_size
         h = C.c_void_p()
-        rc = self.lib.dsm_asr_create(C.byref(cfg), device_id, batch_size, lm_path.encode(), mimi_path.encode(),
-                                     C.byref(h))
+        if arena is not None:
+            ptr, nbytes, manifest = arena[0], arena[1], bytes(arena[2])
+            self._arena_keepalive = arena[3] if len(arena) > 3 else None
+            mbuf = (C.c_uint8 * max(len(manifest), 1)).from_buffer_copy(manifest or b"\0")
+            rc = self.lib.dsm_asr_create_from_arena(C.byref(cfg), device_id, batch_size, C.c_void_p(ptr), nbytes, mbuf,
+                                                    len(manifest), C.byref(h))
+        else:
+            rc = self.lib.dsm_asr_create(C.byref(cfg), device_id, batch_size, lm_path.encode(), mimi_path.encode(),
+                                         C.byref(h))
         if rc != 0:
             msg = self.lib.dsm_last_error(None)
             raise DsmError(f"dsm_asr_create failed ({rc}): {msg.decode() if msg else '?'}")
         self.h = h
         self.n_q = self.lib.dsm_n_q(h)
+
+    def weight_arena(self):
+        """(device pointer, nbytes, manifest bytes) of this engine's packed weight arena (dsm_asr_weight_arena)."""
+        ptr, n, mp, mn = C.c_void_p(), C.c_size_t(), C.c_void_p(), C.c_size_t()
+        self._check(self.lib.dsm_asr_weight_arena(self.h, C.byref(ptr), C.byref(n), C.byref(mp), C.byref(mn)))
+        manifest = C.string_at(mp, mn.value) if mn.value else b""
+        return ptr.value, n.value, manifest
 
     def _check(self, rc):
         if rc < 0:

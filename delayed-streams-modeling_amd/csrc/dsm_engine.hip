@@ -309,6 +309,39 @@ struct dsm_engine {
     HIPCHK_E(this, hipStreamSynchronize(nullptr));
     return 0;
   }
+
+  // ---- weight arena: every immutable weight tensor of the STT engine lives in ONE contiguous device
+  // allocation, carved in load order, so that a multi-GPU launcher can fan the packed weights out with a single RCCL
+  // broadcast and the other ranks attach to the received bytes without reading, converting or packing anything.
+  //   W_PLAIN    no arena: upload_w == upload (the TTS engine)
+  //   W_MEASURE  first pass over the checkpoint: only adds up the carve sizes
+  //   W_LOAD     second pass: carve + host-to-device copy; the answers of the optional-key probes go to `manifest`
+  //   W_ATTACH   carve only: the bytes are already there (received arena); probes replay `manifest`
+  enum WeightMode { W_PLAIN = 0, W_MEASURE, W_LOAD, W_ATTACH };
+  WeightMode wmode = W_PLAIN;
+  char* arena = nullptr;
+  size_t arena_size = 0, arena_off = 0;
+  bool arena_owned = false;
+  std::vector<uint8_t> manifest;
+  size_t manifest_pos = 0;
+  template <typename T>
+  int upload_w(T** out, const T* host, size_t count) {
+    if (wmode == W_PLAIN) return upload(out, host, count);
+    const size_t bytes = (count * sizeof(T) + 256 + 255) & ~(size_t)255;  // same slack as dalloc, 256-byte aligned carves
+    if (wmode != W_MEASURE) {
+      if (arena_off + bytes > arena_size) {
+        set_error("weight arena too small: need %zu bytes at offset %zu of %zu (config / manifest mismatch?)", bytes, arena_off, arena_size);
+        return DSM_ERR_INVALID;
+      }
+      *out = reinterpret_cast<T*>(arena + arena_off);
+      if (wmode == W_LOAD) HIPCHK_E(this, hipMemcpy(*out, host, count * sizeof(T), hipMemcpyHostToDevice));
+    } else {
+      *out = nullptr;
+    }
+    arena_off += bytes;
+    return 0;
+  }
+  bool skip_host_weights() const { return wmode == W_MEASURE || wmode == W_ATTACH; }
 };
 
 // ----------------------------------------------------------------------------------------------
@@ -327,7 +360,7 @@ struct Loader {
     vsnprintf(name, sizeof name, fmt, ap);
     va_end(ap);
     std::vector<float> out((size_t)numel);
-    if (failed) return out;
+    if (failed || e->skip_host_weights()) return out;  // measure / attach: sizes only, nothing is read
     char err[512];
     if (dsm_st_read_f32(f, name, numel, out.data(), err, sizeof err)) {
       e->set_error("%s", err);
@@ -341,7 +374,13 @@ struct Loader {
     va_start(ap, fmt);
     vsnprintf(name, sizeof name, fmt, ap);
     va_end(ap);
-    return dsm_st_find(f, name) != nullptr;
+    if (e->wmode == dsm_engine::W_ATTACH) {  // no checkpoint on this rank: replay the loading rank's answers, in order
+      if (e->manifest_pos >= e->manifest.size()) { failed = true; e->set_error("weight manifest exhausted"); return false; }
+      return e->manifest[e->manifest_pos++] != 0;
+    }
+    const bool found = dsm_st_find(f, name) != nullptr;
+    if (e->wmode == dsm_engine::W_LOAD) e->manifest.push_back(found ? 1 : 0);
+    return found;
   }
 };
 
@@ -355,24 +394,27 @@ int pack_linear(dsm_engine* e, Linear* L, const float* w, int N, int K, bool bf1
   L->Kpad = round_up(K, 32);
   L->bf16 = bf16;
   size_t n = (size_t)L->Npad * L->Kpad;
+  const bool skip = e->skip_host_weights();
   if (bf16) {
-    std::vector<uint16_t> p(n, 0);
-    for (int i = 0; i < N; ++i)
-      for (int j = 0; j < K; ++j) p[(size_t)i * L->Kpad + j] = dsm_f32_to_bf16(w[(size_t)i * K + j]);
+    std::vector<uint16_t> p(skip ? 0 : n, 0);
+    if (!skip)
+      for (int i = 0; i < N; ++i)
+        for (int j = 0; j < K; ++j) p[(size_t)i * L->Kpad + j] = dsm_f32_to_bf16(w[(size_t)i * K + j]);
     uint16_t* d = nullptr;
-    if (int rc = e->upload(&d, p.data(), n)) return rc;
+    if (int rc = e->upload_w(&d, p.data(), n)) return rc;
     L->w = d;
   } else {
-    std::vector<float> p(n, 0.0f);
-    for (int i = 0; i < N; ++i) memcpy(&p[(size_t)i * L->Kpad], &w[(size_t)i * K], sizeof(float) * K);
+    std::vector<float> p(skip ? 0 : n, 0.0f);
+    if (!skip)
+      for (int i = 0; i < N; ++i) memcpy(&p[(size_t)i * L->Kpad], &w[(size_t)i * K], sizeof(float) * K);
     float* d = nullptr;
-    if (int rc = e->upload(&d, p.data(), n)) return rc;
+    if (int rc = e->upload_w(&d, p.data(), n)) return rc;
     L->w = d;
   }
   if (bias) {
     std::vector<float> pb((size_t)L->Npad, 0.0f);
     memcpy(pb.data(), bias, sizeof(float) * N);
-    if (int rc = e->upload(&L->bias, pb.data(), pb.size())) return rc;
+    if (int rc = e->upload_w(&L->bias, pb.data(), pb.size())) return rc;
   }
   return 0;
 }
@@ -429,7 +471,7 @@ int load_transformer(dsm_engine* e, Loader& ld, TransformerW* t, const dsm_trans
   std::vector<float> inv(hd / 2);
   for (int i = 0; i < hd / 2; ++i)  // RotaryEmbedding::new — core/transformer.rs:386-392
     inv[i] = (float)(1.0 / pow((double)cfg.max_period, (double)(2 * i) / (double)hd));
-  if (int rc = e->upload(&t->inv_freq, inv.data(), inv.size())) return rc;
+  if (int rc = e->upload_w(&t->inv_freq, inv.data(), inv.size())) return rc;
   for (int l = 0; l < cfg.num_layers; ++l) {
     TLayerW& L = t->layers[l];
     {
@@ -456,9 +498,9 @@ int load_transformer(dsm_engine* e, Loader& ld, TransformerW* t, const dsm_trans
           wv = ld.get(d, "%s.layers.%d.norm%d.weight", prefix, l, which);
       }
       if (ld.failed) return DSM_ERR_IO;
-      if (int rc = e->upload(w, wv.data(), wv.size())) return rc;
+      if (int rc = e->upload_w(w, wv.data(), wv.size())) return rc;
       if (!bv.empty())
-        if (int rc = e->upload(b, bv.data(), bv.size())) return rc;
+        if (int rc = e->upload_w(b, bv.data(), bv.size())) return rc;
     }
     if (cfg.gating) {
       auto wi = ld.get((int64_t)2 * t->hidden * d, "%s.layers.%d.gating.linear_in.weight", prefix, l);
@@ -479,8 +521,8 @@ int load_transformer(dsm_engine* e, Loader& ld, TransformerW* t, const dsm_trans
       auto s1 = ld.get(d, "%s.layers.%d.layer_scale_1.scale", prefix, l);
       auto s2 = ld.get(d, "%s.layers.%d.layer_scale_2.scale", prefix, l);
       if (ld.failed) return DSM_ERR_IO;
-      if (int rc = e->upload(&L.ls1, s1.data(), s1.size())) return rc;
-      if (int rc = e->upload(&L.ls2, s2.data(), s2.size())) return rc;
+      if (int rc = e->upload_w(&L.ls1, s1.data(), s1.size())) return rc;
+      if (int rc = e->upload_w(&L.ls2, s2.data(), s2.size())) return rc;
     }
   }
   return 0;
@@ -641,7 +683,7 @@ int load_mimi(dsm_engine* e, Loader& ld, MimiW* m, const dsm_mimi_config& cfg) {
           for (int kk = 0; kk < st.k; ++kk)
             r[((size_t)kk * st.out_c + co) * st.in_c + ci] = w[((size_t)ci * st.out_c + co) * st.k + kk];
       if (int rc = pack_linear(e, &st.up, r.data(), st.k * st.out_c, st.in_c, false, nullptr)) return rc;
-      if (int rc = e->upload(&st.up_bias, b.data(), b.size())) return rc;
+      if (int rc = e->upload_w(&st.up_bias, b.data(), b.size())) return rc;
       idx += 2;
       T *= ratio;
       const int dim = st.out_c, hidden = dim / cfg.compress;
@@ -667,11 +709,12 @@ int load_mimi(dsm_engine* e, Loader& ld, MimiW* m, const dsm_mimi_config& cfg) {
     std::vector<float> ur((size_t)2 * st_ * dim);
     for (int c = 0; c < dim; ++c)
       for (int kk = 0; kk < 2 * st_; ++kk) ur[(size_t)kk * dim + c] = uw[(size_t)c * 2 * st_ + kk];
-    if (int rc = e->upload(&m->upsample_w, ur.data(), ur.size())) return rc;
+    if (int rc = e->upload_w(&m->upsample_w, ur.data(), ur.size())) return rc;
     std::vector<const float*> ptrs;
     ptrs.push_back(reinterpret_cast<const float*>(m->rvq_first.codebooks[0].w));
     for (auto& cb : m->rvq_rest.codebooks) ptrs.push_back(reinterpret_cast<const float*>(cb.w));
-    if (int rc = e->upload(&m->emb_ptrs, ptrs.data(), ptrs.size())) return rc;
+    if (e->wmode != dsm_engine::W_MEASURE)  // a table of device pointers: per engine, never part of the arena
+      if (int rc = e->upload(&m->emb_ptrs, ptrs.data(), ptrs.size())) return rc;
   }
   return 0;
 }

@@ -52,5 +52,59 @@ def broadcast_bytes(raw, src, dist, device=None, chunk_bytes=512 << 20):
     return out
 
 
+class _DevicePtrView:
+    """A raw device allocation as a uint8 array for torch.as_tensor (zero copy, `__cuda_array_interface__` v2)."""
+
+    def __init__(self, ptr, nbytes, owner):
+        self._owner = owner  # keeps the allocation alive as long as the view is
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def broadcast_tensor_(t, src, dist, chunk_bytes=1 << 30):
+    """In-place broadcast of a flat uint8 tensor (device or host) in pieces of `chunk_bytes`: xGMI is point to point
+    (7 links x ~153 GB/s per GPU), a ring broadcast is per-link bound, and 1 GiB pieces keep RCCL's ring pipelined
+    without any 2^31-element limit in the way."""
+    n = t.numel()
+    for lo in range(0, n, chunk_bytes):
+        dist.broadcast(t[lo:min(n, lo + chunk_bytes)], src)
+    return t
+
+
+def fan_out_engine(dsm, cfg, batch_size, lm_path, mimi_path, dist, device, src=0):
+    """One engine per rank with ONE collective at load: rank `src` reads the safetensors and packs the
+    weights into its device arena (dsm_asr_create); the arena bytes and the loader manifest travel over RCCL (xGMI) and
+    the other ranks attach to them (dsm_asr_create_from_arena) — no file, no conversion, no host copy on their side.
+    Returns (engine, stats) with stats = {"arena_bytes", "broadcast_ms", "ranks"}."""
+    import time
+    import torch
+    rank, world = dist.get_rank(), dist.get_world_size()
+    eng, manifest = None, b""
+    hdr = torch.zeros(2, dtype=torch.int64, device=device)
+    if rank == src:
+        eng = dsm.AsrEngine(cfg, batch_size, lm_path, mimi_path, device_id=device.index or 0)
+        ptr, nbytes, manifest = eng.weight_arena()
+        hdr[0], hdr[1] = nbytes, len(manifest)
+    dist.broadcast(hdr, src)
+    nbytes, mlen = int(hdr[0].item()), int(hdr[1].item())
+    mt = torch.frombuffer(bytearray(manifest), dtype=torch.uint8).to(device) if rank == src and mlen else torch.zeros(max(mlen, 1), dtype=torch.uint8, device=device)
+    dist.broadcast(mt, src)
+    if rank == src:
+        arena = torch.as_tensor(_DevicePtrView(ptr, nbytes, eng), device=device)
+    else:
+        arena = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    torch.cuda.synchronize(device)
+    dist.barrier()
+    t0 = time.perf_counter()
+    broadcast_tensor_(arena, src, dist)
+    torch.cuda.synchronize(device)
+    dist.barrier()
+    ms = (time.perf_counter() - t0) * 1000.0
+    if rank != src:
+        manifest = bytes(mt[:mlen].cpu().numpy().tobytes())
+        eng = dsm.AsrEngine(cfg, batch_size, device_id=device.index or 0, arena=(arena.data_ptr(), nbytes, manifest, arena))
+    return eng, {"arena_bytes": nbytes, "broadcast_ms": ms, "ranks": world}
+
+
 def digest(raw):
     return hashlib.sha256(np.ascontiguousarray(raw).tobytes()).hexdigest()

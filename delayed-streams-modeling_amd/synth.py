@@ -31,6 +31,8 @@ def _rng(name, seed):
 
 
 class Spec:
+    weight_norm = False
+
     def __init__(self):
         self.items = []  # (name, shape, kind, param)
 
@@ -47,6 +49,8 @@ def _gen(name, shape, kind, param, seed):
         return (1.0 + 0.02 * r.standard_normal(n, dtype=np.float32)).astype(np.float32).reshape(shape)
     if kind == "const":
         return np.full(shape, param, dtype=np.float32)
+    if kind == "gain":  # weight-norm gains: row norms of ~1 (unit-variance layer outputs), spread by `param`
+        return (1.0 + param * (2.0 * r.random(n, dtype=np.float32) - 1.0)).astype(np.float32).reshape(shape)
     raise ValueError(kind)
 
 
@@ -180,18 +184,29 @@ def make_synth_tts_weights(cfg, out_dir, seed=SEED, tag="tts"):
 
 
 def _conv(s, prefix, out_c, in_c, k, bias=True):
-    s.add(f"{prefix}.conv.conv.weight", (out_c, in_c, k), "normal", (in_c * k) ** -0.5)
+    if s.weight_norm:  # un-folded: weight = weight_v * weight_g / ||weight_v||_(1,2)  (core/conv.rs:35-43)
+        s.add(f"{prefix}.conv.conv.weight_g", (out_c, 1, 1), "gain", 0.25)
+        s.add(f"{prefix}.conv.conv.weight_v", (out_c, in_c, k), "normal", 0.7)
+    else:
+        s.add(f"{prefix}.conv.conv.weight", (out_c, in_c, k), "normal", (in_c * k) ** -0.5)
     if bias:
         s.add(f"{prefix}.conv.conv.bias", (out_c,), "normal", 0.02)
 
 
 def _convtr(s, prefix, in_c, out_c, k):
-    s.add(f"{prefix}.convtr.convtr.weight", (in_c, out_c, k), "normal", (in_c * k) ** -0.5)
+    if s.weight_norm:  # norm over dims (1, 2) of [in_c, out_c, k]: one gain per INPUT channel (core/conv.rs:133-139)
+        s.add(f"{prefix}.convtr.convtr.weight_g", (in_c, 1, 1), "gain", 0.25)
+        s.add(f"{prefix}.convtr.convtr.weight_v", (in_c, out_c, k), "normal", 0.7)
+    else:
+        s.add(f"{prefix}.convtr.convtr.weight", (in_c, out_c, k), "normal", (in_c * k) ** -0.5)
     s.add(f"{prefix}.convtr.convtr.bias", (out_c,), "normal", 0.02)
 
 
-def mimi_spec(m):
+def mimi_spec(m, weight_norm=False):
+    """weight_norm: store the SEANet convs / transposed convs as `weight_g` + `weight_v` like the published Mimi
+    checkpoint does (the loader folds them: core/conv.rs:27-45,130-141) instead of the pre-folded `weight`."""
     s = Spec()
+    s.weight_norm = weight_norm
     nf, ratios = m.n_filters, [m.ratios[i] for i in range(m.n_ratios)]
     # encoder — core/seanet.rs:169-252
     idx, mult = 0, 1
@@ -242,16 +257,16 @@ def mimi_spec(m):
     return s
 
 
-def make_synth_weights(cfg, out_dir, seed=SEED, tag="model"):
+def make_synth_weights(cfg, out_dir, seed=SEED, tag="model", weight_norm=False):
     """Writes <out_dir>/<tag>.lm.safetensors (BF16) and <tag>.mimi.safetensors (F32); returns the two paths.
-    Skips files that already exist (generation is deterministic in (cfg, seed))."""
+    Skips files that already exist (generation is deterministic in (cfg, seed)).  weight_norm: see mimi_spec."""
     os.makedirs(out_dir, exist_ok=True)
     lm_path = os.path.join(out_dir, f"{tag}.lm.safetensors")
-    mimi_path = os.path.join(out_dir, f"{tag}.mimi.safetensors")
+    mimi_path = os.path.join(out_dir, f"{tag}.mimi{'_wn' if weight_norm else ''}.safetensors")
     if not os.path.exists(lm_path):
         write_safetensors(lm_path, lm_spec(cfg), "BF16", seed)
     if not os.path.exists(mimi_path):
-        write_safetensors(mimi_path, mimi_spec(cfg.mimi), "F32", seed)
+        write_safetensors(mimi_path, mimi_spec(cfg.mimi, weight_norm), "F32", seed)
     return lm_path, mimi_path
 
 

@@ -135,6 +135,20 @@ void dsm_destroy(dsm_engine*);
 const char* dsm_last_error(const dsm_engine*); /* NULL engine -> last create error */
 
 /*
+ * Multi-GPU load (the reference is single-device: srv/main.rs:317-327).  Every immutable weight
+ * tensor of an engine lives in ONE contiguous device allocation (the "weight arena": packed bf16 LM matrices, f32 Mimi
+ * matrices, folded codebooks, norms — 2.0 GB for stt-1b-en_fr), carved in load order.  The rank that read the
+ * safetensors exposes it with dsm_asr_weight_arena; the launcher broadcasts those bytes once (RCCL over xGMI: the only
+ * collective of the whole path) together with the small manifest (the answers of the loader's optional-key probes, one
+ * byte each), and every other rank attaches with dsm_asr_create_from_arena: no file, no conversion, no packing, no
+ * host copy.  The arena handed to dsm_asr_create_from_arena stays owned by the caller and must outlive the engine; it
+ * must sit on device `device_id`.  Configuration and batch size may differ per rank only in batch_size.
+ */
+int dsm_asr_weight_arena(dsm_engine*, void** d_arena, size_t* arena_bytes, const uint8_t** manifest, size_t* manifest_bytes);
+int dsm_asr_create_from_arena(const dsm_asr_config* cfg, int device_id, int batch_size, const void* d_arena,
+                              size_t arena_bytes, const uint8_t* manifest, size_t manifest_bytes, dsm_engine** out);
+
+/*
  * Mimi::encode_step(&StreamTensor, &StreamMask) — core/mimi.rs:195-206, called at
  * srv/batched_asr.rs:362 (encoder thread).  pcm: host [B*1920] f32; mask: host [B] u8;
  * codes_out: host [B*n_q] u32 (slot-major, [B, n_q, 1] like the reference) or NULL to keep

@@ -82,43 +82,57 @@ float orc_dot(const float* x, const float* w, int K) {
 }
 
 /* y[m*ldy + n] = orc_dot(x + m*ldx, W + n*ldw, K) + bias[n]   (bias may be NULL)
- * Same arithmetic as orc_dot, arranged so that 64 rows advance together (vectorises). */
+ * Same arithmetic as orc_dot, arranged so that MB rows advance together (vectorises); MB is the smallest of
+ * 8 / 16 / 32 / 64 that holds the batch, so that a 5-row test batch does not pay for 64 lanes. */
+#define ORC_LINEAR_BODY(MB)                                                                                   \
+  static void orc_linear_mb##MB(float* y, int ldy, const float* x, int ldx, const float* W, int ldw,          \
+                                const float* bias, int M, int N, int K, const int* ord) {                     \
+    float* xT = (float*)xmalloc(sizeof(float) * (size_t)K * MB);                                              \
+    for (int m0 = 0; m0 < M; m0 += MB) {                                                                      \
+      int mb = MINI(MB, M - m0);                                                                              \
+      for (int kk = 0; kk < K; ++kk) {                                                                        \
+        int k = ord[kk];                                                                                      \
+        for (int mi = 0; mi < MB; ++mi) xT[(size_t)kk * MB + mi] = mi < mb ? x[(size_t)(m0 + mi) * ldx + k] : 0.0f; \
+      }                                                                                                       \
+      _Pragma("omp parallel for schedule(static)")                                                            \
+      for (int n = 0; n < N; ++n) {                                                                           \
+        const float* wr = W + (size_t)n * ldw;                                                                \
+        float total[MB], acc[MB];                                                                             \
+        /* position kk in visiting order <-> chunk: a chunk holds the k in [c0, c1), and the                  \
+         * visiting order never leaves a chunk before it is finished. */                                      \
+        int kk = 0;                                                                                           \
+        for (int c0 = 0; c0 < K; c0 += DSM_KC) {                                                              \
+          int c1 = MINI(c0 + DSM_KC, K);                                                                      \
+          for (int mi = 0; mi < MB; ++mi) acc[mi] = 0.0f;                                                     \
+          for (int cnt = c1 - c0; cnt > 0; --cnt, ++kk) {                                                     \
+            float wv = wr[ord[kk]];                                                                           \
+            const float* xr = xT + (size_t)kk * MB;                                                           \
+            for (int mi = 0; mi < MB; ++mi) acc[mi] = DSM_FMAF(xr[mi], wv, acc[mi]);                          \
+          }                                                                                                   \
+          if (c0 == 0)                                                                                        \
+            for (int mi = 0; mi < MB; ++mi) total[mi] = acc[mi];                                              \
+          else                                                                                                \
+            for (int mi = 0; mi < MB; ++mi) total[mi] = total[mi] + acc[mi];                                  \
+        }                                                                                                     \
+        float bv = bias ? bias[n] : 0.0f;                                                                     \
+        for (int mi = 0; mi < mb; ++mi) y[(size_t)(m0 + mi) * ldy + n] = bias ? total[mi] + bv : total[mi];   \
+      }                                                                                                       \
+    }                                                                                                         \
+    free(xT);                                                                                                 \
+  }
+ORC_LINEAR_BODY(8)
+ORC_LINEAR_BODY(16)
+ORC_LINEAR_BODY(32)
+ORC_LINEAR_BODY(64)
+#undef ORC_LINEAR_BODY
+
 void orc_linear(float* y, int ldy, const float* x, int ldx, const float* W, int ldw, const float* bias, int M,
                 int N, int K) {
   int* ord = dot_order(K);
-  enum { MB = 64 };
-  float* xT = (float*)xmalloc(sizeof(float) * (size_t)K * MB);
-  for (int m0 = 0; m0 < M; m0 += MB) {
-    int mb = MINI(MB, M - m0);
-    for (int kk = 0; kk < K; ++kk) {
-      int k = ord[kk];
-      for (int mi = 0; mi < MB; ++mi) xT[(size_t)kk * MB + mi] = mi < mb ? x[(size_t)(m0 + mi) * ldx + k] : 0.0f;
-    }
-#pragma omp parallel for schedule(static)
-    for (int n = 0; n < N; ++n) {
-      const float* wr = W + (size_t)n * ldw;
-      float total[MB], acc[MB];
-      /* position kk in visiting order <-> chunk: a chunk holds the k in [c0, c1), and the
-       * visiting order never leaves a chunk before it is finished. */
-      int kk = 0;
-      for (int c0 = 0; c0 < K; c0 += DSM_KC) {
-        int c1 = MINI(c0 + DSM_KC, K);
-        for (int mi = 0; mi < MB; ++mi) acc[mi] = 0.0f;
-        for (int cnt = c1 - c0; cnt > 0; --cnt, ++kk) {
-          float wv = wr[ord[kk]];
-          const float* xr = xT + (size_t)kk * MB;
-          for (int mi = 0; mi < MB; ++mi) acc[mi] = DSM_FMAF(xr[mi], wv, acc[mi]);
-        }
-        if (c0 == 0)
-          for (int mi = 0; mi < MB; ++mi) total[mi] = acc[mi];
-        else
-          for (int mi = 0; mi < MB; ++mi) total[mi] = total[mi] + acc[mi];
-      }
-      float bv = bias ? bias[n] : 0.0f;
-      for (int mi = 0; mi < mb; ++mi) y[(size_t)(m0 + mi) * ldy + n] = bias ? total[mi] + bv : total[mi];
-    }
-  }
-  free(xT);
+  if (M <= 8) orc_linear_mb8(y, ldy, x, ldx, W, ldw, bias, M, N, K, ord);
+  else if (M <= 16) orc_linear_mb16(y, ldy, x, ldx, W, ldw, bias, M, N, K, ord);
+  else if (M <= 32) orc_linear_mb32(y, ldy, x, ldx, W, ldw, bias, M, N, K, ord);
+  else orc_linear_mb64(y, ldy, x, ldx, W, ldw, bias, M, N, K, ord);
   free(ord);
 }
 

@@ -59,3 +59,37 @@ def test_decode_after_encode_roundtrip_runs(gpu, dsm, lib, orc, tiny_weights):
         assert np.array_equal(out_e.view(np.uint32), out_o.view(np.uint32))
     eng.close()
     ora.close()
+
+
+def test_weight_g_weight_v_checkpoint(gpu, dsm, lib, orc):
+    """The un-folded checkpoint layout (`weight_g` + `weight_v` for every SEANet conv and transposed conv, as the
+    published Mimi file stores them): the engine's load-time fold (core/conv.rs:27-45 per output channel, :130-141 per
+    input channel) against the oracle's — encode codes + latent and decoded PCM, bit for bit, with a mask and a reset."""
+    import os
+    from dsm_amd import synth
+    cfg = dsm.config_tiny()
+    lm, mimi = synth.make_synth_weights(cfg, os.environ.get("DSM_WEIGHTS_DIR", "/tmp/dsm_weights"), tag="tiny", weight_norm=True)
+    assert mimi.endswith("_wn.safetensors")
+    keys = synth.read_safetensors(mimi).keys()
+    assert not any(k.endswith("conv.conv.weight") and k.startswith(("encoder.", "decoder.")) for k in keys)
+    assert sum(k.endswith("weight_g") for k in keys) == sum(k.endswith("weight_v") for k in keys) >= 20
+    B = 3
+    eng = dsm.AsrEngine(cfg, B, lm, mimi)
+    ora = orc.OracleAsr(cfg, B, lm, mimi)
+    pcm = synth.synth_pcm(B, 10)
+    for s in range(10):
+        if s == 6:
+            eng.mimi_reset_batch_idx(2)
+            ora.mimi_reset_batch_idx(2, side=0)
+        mask = np.array([1, s % 3 != 1, 1], dtype=np.uint8)
+        act = mask.astype(bool)
+        ce, co = eng.encode_step(pcm[s], mask), ora.encode_step(pcm[s], mask)
+        le = eng.debug_read("mimi.latent", B * cfg.mimi.dimension).reshape(B, -1)
+        lo = ora.debug_read("mimi.latent", B * cfg.mimi.dimension).reshape(B, -1)
+        assert np.array_equal(le[act].view(np.uint32), lo[act].view(np.uint32)), f"latent differs at step {s}"
+        assert np.array_equal(ce[act], co[act]), f"codes differ at step {s}"
+        dc = np.where(act[:, None], co, 0).astype(np.uint32)
+        pe, po = eng.decode_step(dc, mask), ora.decode_step(dc, mask, side=0)
+        assert np.array_equal(pe[act].view(np.uint32), po[act].view(np.uint32)), f"decoded PCM differs at step {s}"
+    eng.close()
+    ora.close()

@@ -186,3 +186,78 @@ def test_streaming_decode_matches_hf_whole_clip(dsm, orc, models):
     rms = float(np.sqrt(np.mean((got[:n].astype(np.float64) - audio[:n]) ** 2)))
     print(f"decoded PCM RMS error vs HF: {rms:.3e} (signal RMS {float(np.sqrt(np.mean(audio[:n].astype(np.float64) ** 2))):.3f})")
     assert rms <= 1e-4 * max(1.0, float(np.sqrt(np.mean(audio[:n].astype(np.float64) ** 2)))), f"decoded PCM RMS error {rms}"
+
+
+def test_weight_g_weight_v_checkpoint_matches_hf_weight_norm(dsm, orc, models, tmp_path):
+    """The published Mimi checkpoint stores the SEANet convs un-folded (`weight_g`, `weight_v`); the loader folds them
+    (core/conv.rs:27-45: conv, norm over dims (1,2) per OUTPUT channel; :130-141: transposed conv, per INPUT channel).
+    HF's own weight-norm parametrisation (torch.nn.utils.parametrizations.weight_norm — the function the reference's
+    comment points at) is applied to every SEANet conv of the HF model, the gains are scaled away from ||v|| so that
+    the fold is not the identity, and the un-folded tensors are exported under the reference's key names: the oracle's
+    streaming encode / decode must still follow HF's whole-clip results."""
+    cfg, hf_folded, lm_path, _ = models
+    import copy
+    hf = copy.deepcopy(hf_folded)
+    n_wn = 0
+    for mod in hf.modules():
+        if hasattr(mod, "apply_weight_norm") and mod is not hf and type(mod).__name__ in ("MimiConv1d", "MimiConvTranspose1d"):
+            name = [k for k, v in hf.named_modules() if v is mod][0]
+            if name.startswith(("encoder.", "decoder.")):  # SEANet only: down/upsample carry plain weights in the reference
+                mod.apply_weight_norm()
+                n_wn += 1
+    assert n_wn >= 20
+    g = torch.Generator().manual_seed(3)
+    sd = hf.state_dict()
+    for k in sd:
+        if k.endswith("parametrizations.weight.original0"):
+            sd[k] = sd[k] * (0.5 + torch.rand(sd[k].shape, generator=g))
+    hf.load_state_dict(sd)
+    hf.eval()
+    # export: folded view of everything first (keys as before), then replace the SEANet weights by their g / v pair
+    plain = {}
+    for k, v in hf.state_dict().items():
+        if "parametrizations.weight.original" in k:
+            continue
+        plain[k] = v
+    for name, mod in hf.named_modules():
+        if hasattr(mod, "parametrizations") and "weight" in getattr(mod, "parametrizations", {}):
+            plain[name + ".weight"] = mod.weight.detach()
+    ref = hf_to_reference_keys(plain, cfg.mimi.transformer.num_heads)
+    n_unfolded = 0
+    for name, mod in hf.named_modules():
+        if hasattr(mod, "parametrizations") and "weight" in getattr(mod, "parametrizations", {}):
+            one = hf_to_reference_keys({name + ".weight": mod.weight.detach(), **{k: v for k, v in plain.items() if k.startswith("decoder.layers.")}},
+                                       cfg.mimi.transformer.num_heads)
+            key = [k for k in one if k.startswith(name.replace(".layers.", ".model.").rsplit(".conv", 1)[0]) and k.endswith(".weight")]
+            key = [k for k in key if np.array_equal(one[k], mod.weight.detach().numpy())][0]
+            del ref[key]
+            ref[key + "_g"] = mod.parametrizations.weight.original0.detach().numpy().astype(np.float32)
+            ref[key + "_v"] = mod.parametrizations.weight.original1.detach().numpy().astype(np.float32)
+            assert ref[key + "_g"].shape == (ref[key + "_v"].shape[0], 1, 1)
+            n_unfolded += 1
+    assert n_unfolded == n_wn
+    path = os.path.join(tmp_path, "hf_wn.mimi.safetensors")
+    write_f32_safetensors(path, ref)
+    steps = 8
+    rng = np.random.default_rng(5)
+    pcm = (0.2 * rng.standard_normal(steps * 1920)).astype(np.float32)
+    codes = rng.integers(0, cfg.mimi.quantizer_bins, (steps, cfg.mimi.quantizer_n_q)).astype(np.int64)
+    with torch.no_grad():
+        x = hf.encoder(torch.from_numpy(pcm)[None, None, :])
+        x = hf.encoder_transformer(x.transpose(1, 2))[0].transpose(1, 2)
+        lat = hf.downsample(x)[0].numpy().T
+        audio = hf.decode(torch.from_numpy(codes.T)[None]).audio_values[0, 0].numpy()
+        lat_folded = hf_folded.downsample(hf_folded.encoder_transformer(hf_folded.encoder(torch.from_numpy(pcm)[None, None, :]).transpose(1, 2))[0].transpose(1, 2))[0].numpy().T
+    assert np.abs(lat - lat_folded).max() > 1e-2, "the scaled gains must change the model, or the test proves nothing"
+    ora = orc.OracleAsr(cfg, 1, lm_path, path)
+    mask = np.ones(1, dtype=np.uint8)
+    for s in range(steps):
+        ora.encode_step(pcm[s * 1920:(s + 1) * 1920][None, :], mask)
+        got = ora.debug_read("mimi.latent", cfg.mimi.dimension)
+        assert np.abs(got - lat[s]).max() <= 2e-4 * max(1.0, np.abs(lat[s]).max()), f"latent of frame {s} differs from HF (weight-norm checkpoint)"
+    got = np.concatenate([ora.decode_step(codes[s][None, :].astype(np.uint32), mask)[0] for s in range(steps)])
+    ora.close()
+    n = min(got.size, audio.size)
+    sig = float(np.sqrt(np.mean(audio[:n].astype(np.float64) ** 2)))
+    rms = float(np.sqrt(np.mean((got[:n].astype(np.float64) - audio[:n]) ** 2)))
+    assert rms <= 1e-4 * max(1.0, sig), f"decoded PCM RMS error {rms} (weight-norm checkpoint)"

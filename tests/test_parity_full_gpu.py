@@ -74,6 +74,28 @@ def test_stt_2_6b_en_shapes(gpu, dsm, lib, orc):
         assert np.array_equal(hid_e.view(np.uint32), hid_o.view(np.uint32))
     eng.close()
     ora.close()
+    # BASELINE.json configs[2] is quoted at batch 128: one LM-only step at B = 34 (two stream groups of 32 + 2 slots;
+    # the first runs bf16 MT = 2 GEMMs and 1024 attention workgroups of hd 64) — codes fed directly, the oracle skips Mimi
+    B = 34
+    rng = np.random.default_rng(9)
+    codes = rng.integers(0, cfg.mimi.quantizer_bins, (B, cfg.audio_codebooks)).astype(np.uint32)
+    mask = np.ones(B, dtype=np.uint8)
+    mask[5] = 0
+    act = mask.astype(bool)
+    eng = dsm.AsrEngine(cfg, B, lm, mimi)
+    assert eng.stream_groups() == [(0, 32), (32, 2)]
+    et, _ = eng.step_tokens(codes, mask)
+    hid_e = eng.debug_read("lm.hidden", B * cfg.lm.d_model).reshape(B, -1)
+    lg_e = eng.debug_read("lm.logits", B * cfg.text_out_vocab_size).reshape(B, -1)
+    eng.close()
+    ora = orc.OracleAsr(cfg, B, lm, mimi)
+    ot, _ = ora.step_tokens(codes, mask)
+    hid_o = ora.debug_read("lm.hidden", B * cfg.lm.d_model).reshape(B, -1)
+    lg_o = ora.debug_read("lm.logits", B * cfg.text_out_vocab_size).reshape(B, -1)
+    ora.close()
+    assert np.array_equal(hid_e[act].view(np.uint32), hid_o[act].view(np.uint32)), "B=34: lm.hidden differs"
+    assert np.array_equal(lg_e[act].view(np.uint32), lg_o[act].view(np.uint32)), "B=34: logits differ"
+    assert np.array_equal(et[act], ot[act])
     for p in (lm,):  # 5 GB: do not leave it in /tmp for the next test session
         os.remove(p)
 
@@ -106,6 +128,28 @@ def test_tts_v202501_shapes(gpu, dsm, lib, orc):
     for b in range(B):
         for i in range(eng.step_idx(b)):
             assert np.array_equal(eng.audio_tokens(b, i), ora.audio_tokens(b, i))
+    eng.close()
+    ora.close()
+    # BASELINE.json configs[4] is quoted at batch 32: two steps at B = 32 with the text-audio delay removed, so that the
+    # batched depformer (32 slices x 32 slots: MT = 2 GEMMs, 16 heads x 32 slots of attention over the slice axis) runs
+    # from the first step
+    cfg.text_audio_delay_in_tokens = 0
+    B = 32
+    eng = dsm.TtsEngine(cfg, B, path)
+    ora = orc.OracleTts(cfg, B, path)
+    for s in range(2):
+        prev = rng.integers(0, cfg.text_in_vocab_size, B).astype(np.uint32)
+        allowed = np.where(np.arange(B) % 3 == 0, dsm.TTS_ALLOW_PAD_OR_EPAD, rng.integers(4, 8000, B)).astype(np.int32)
+        mask = np.ones(B, dtype=np.uint8)
+        mask[7] = 0 if s == 1 else 1
+        act = mask.astype(bool)
+        te, ae = eng.step(prev, allowed, mask)
+        to, ao = ora.step(prev, allowed, mask)
+        he = eng.debug_read("lm.hidden", B * cfg.lm.d_model).reshape(B, -1)
+        ho = ora.debug_read("lm.hidden", B * cfg.lm.d_model).reshape(B, -1)
+        assert np.array_equal(he[act].view(np.uint32), ho[act].view(np.uint32)), f"B=32: LM hidden differs at step {s}"
+        assert np.array_equal(te[act], to[act]), f"B=32: text tokens differ at step {s}"
+        assert np.array_equal(ae[act], ao[act]), f"B=32: depformer tokens differ at step {s}"
     eng.close()
     ora.close()
     os.remove(path)
