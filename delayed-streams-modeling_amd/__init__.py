@@ -102,7 +102,8 @@ class WorkerBackend(C.Structure):
 class Metrics(C.Structure):
     _fields_ = [("last_encode_us", C.c_double), ("last_lm_us", C.c_double),
                 ("algorithmic_bytes_encode", C.c_double), ("algorithmic_bytes_lm", C.c_double),
-                ("steps_encode", C.c_uint64), ("steps_lm", C.c_uint64)]
+                ("steps_encode", C.c_uint64), ("steps_lm", C.c_uint64),
+                ("graph_launches", C.c_uint64), ("eager_bodies", C.c_uint64)]
 
 
 MSG_STEP, MSG_WORD, MSG_END_WORD = 0, 1, 2
@@ -122,7 +123,7 @@ ABI_SYMBOLS = [
     "dsm_worker_create_with_backend", "dsm_worker_destroy", "dsm_worker_last_error", "dsm_worker_set_detokenizer", "dsm_worker_open", "dsm_worker_close",
     "dsm_worker_send", "dsm_worker_step", "dsm_worker_recv", "dsm_worker_buffered",
     "dsm_tts_config_v202501", "dsm_tts_create", "dsm_tts_destroy", "dsm_tts_last_error", "dsm_tts_step",
-    "dsm_tts_audio_tokens", "dsm_tts_step_idx", "dsm_tts_reset_slot", "dsm_tts_debug_read",
+    "dsm_tts_audio_tokens", "dsm_tts_step_idx", "dsm_tts_reset_slot", "dsm_tts_debug_read", "dsm_tts_get_metrics",
 ]
 PROF_TAGS = ["attn_lm", "gemm_lm", "attn_mimi", "gemm_mimi", "rvq", "other"]
 
@@ -232,6 +233,7 @@ def load_library(path=None):
     lib.dsm_tts_step_idx.argtypes = [vp, C.c_int]
     lib.dsm_tts_reset_slot.argtypes = [vp, C.c_int]
     lib.dsm_tts_debug_read.argtypes = [vp, C.c_char_p, fp, C.c_size_t]
+    lib.dsm_tts_get_metrics.argtypes = [vp, C.POINTER(Metrics)]
     for name in ("dsm_tts_create", "dsm_tts_step", "dsm_tts_audio_tokens", "dsm_tts_step_idx", "dsm_tts_reset_slot",
                  "dsm_tts_debug_read"):
         getattr(lib, name).restype = C.c_int
@@ -749,3 +751,8 @@ class TtsEngine:
         out = np.zeros(n, dtype=np.float32)
         got = self._check(self.lib.dsm_tts_debug_read(self.h, name.encode(), _ptr(out), n))
         return out[:got]
+
+    def metrics(self):
+        m = Metrics()
+        self._check(self.lib.dsm_tts_get_metrics(self.h, C.byref(m)))
+        return m

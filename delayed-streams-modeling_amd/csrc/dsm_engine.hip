@@ -186,6 +186,8 @@ struct dsm_engine {
   bool grp_busy = false;
   bool fuse_qkv = true;  // DSM_FUSE_QKV=0: keep the separate QKV reduce launch
   bool chunk_loop = true;  // DSM_CHUNK_LOOP=0: always split K across workgroups
+  bool roll_prefetch = true;  // DSM_ROLL=0: the chunk loop requests a chunk only after finishing the previous one (r01 behaviour)
+  int loop_depth = 4;         // DSM_LOOP_DEPTH=2: two-block rolling window (fewer registers, three waves per SIMD) where four is the default
   size_t attn_lds_pad = 60000;  // DSM_ATTN_LDS_PAD: extra dynamic LDS per attention workgroup of a large launch (2 per CU)
   int chunk_loop_min_tiles = 384;  // DSM_CHUNK_LOOP_MIN (swept at B = 512 / 1024: 384 best)
   int prio_hi = 0;
@@ -217,6 +219,22 @@ struct dsm_engine {
   static constexpr int kStreams = 1 + kMaxGroups;
   float* gemm_ws[kStreams] = {};
   size_t gemm_ws_cap[kStreams] = {};
+  uint64_t ws_gen = 0;  // bumped whenever a workspace moves: captured graphs hold the old pointer
+  // hipGraph replay of the launch-bound inner loops: the kernel sequence of one Mimi encode / decode,
+  // of one LM stream group's transformer + heads, of one TTS step is captured once its shapes, pointers and first-call
+  // branches have settled (two eager runs), then replayed with ONE hipGraphLaunch — ~150 kernel nodes for ~12 us of
+  // host time instead of ~3.5 us each.  Every per-step variable already lives in device buffers, so the captured
+  // arguments never change.  DSM_GRAPHS=0 keeps the eager path; profiling brackets force it too.
+  struct GraphSlot {
+    hipGraphExec_t exec = nullptr;
+    uint64_t key = 0, ws_gen = 0;
+    int warm = 0;
+    bool disabled = false;
+  };
+  bool use_graphs = true;
+  bool capturing = false, capture_failed = false;
+  GraphSlot g_enc[2], g_grp[kMaxGroups], g_dec, g_tts[2];
+  uint64_t graph_launches = 0, eager_bodies = 0;
   // per-kernel-class event timing (dsm_prof_*)
   unsigned prof_mask = 0;
   // one slot per stream (0 = encoder, 1 = model): the two host threads of the worker never share a slot
@@ -801,6 +819,12 @@ int launch_gemm_tiled(dsm_engine* e, hipStream_t st, GemmArgs& a) {
     const int wsid = e->sid(st);
     size_t need = (size_t)chunks * mtiles * a.ws_ntiles * 256 * sizeof(float);
     if (need > e->gemm_ws_cap[wsid]) {  // first use of a bigger shape: grow (never happens in steady state)
+      if (e->capturing) {  // a graph capture cannot allocate: give up on this capture, the caller reruns the body eagerly
+        e->capture_failed = true;
+        e->set_error("split-K workspace grew during a graph capture");
+        return DSM_ERR_STATE;
+      }
+      e->ws_gen += 1;
       HIPCHK(hipStreamSynchronize(st));
       if (e->gemm_ws[wsid]) HIPCHK(hipFree(e->gemm_ws[wsid]));
       e->gemm_ws[wsid] = nullptr;
@@ -814,12 +838,15 @@ int launch_gemm_tiled(dsm_engine* e, hipStream_t st, GemmArgs& a) {
   }
   dim3 grid(gx, chunks, (a.M + 16 * MT - 1) / (16 * MT));
   const int ph = e->prof_begin(e->tag_gemm[e->sid(st)], st);
-  if (MT == 4)
-    hipLaunchKernelGGL((gemm_tile_kernel<WT, KVT, 4, NT, EPI>), grid, dim3(256), 0, st, a);
-  else if (MT == 2)
-    hipLaunchKernelGGL((gemm_tile_kernel<WT, KVT, 2, NT, EPI>), grid, dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL((gemm_tile_kernel<WT, KVT, 1, NT, EPI>), grid, dim3(256), 0, st, a);
+  const bool roll = a.chunk_loop > 1 && e->roll_prefetch;  // whole K in the workgroup with a rolling load window
+  constexpr int DMAX = LoopDepth<WT, NT>::MAX;
+  const bool deep = DMAX == 4 && e->loop_depth == 4;
+#define DSM_LAUNCH_TILED(MTv)                                                                                   \
+  if (roll && deep) hipLaunchKernelGGL((gemm_loop_kernel<WT, KVT, MTv, NT, EPI, DMAX>), grid, dim3(256), 0, st, a); \
+  else if (roll) hipLaunchKernelGGL((gemm_loop_kernel<WT, KVT, MTv, NT, EPI, 2>), grid, dim3(256), 0, st, a);       \
+  else hipLaunchKernelGGL((gemm_tile_kernel<WT, KVT, MTv, NT, EPI>), grid, dim3(256), 0, st, a);
+  if (MT == 4) { DSM_LAUNCH_TILED(4) } else if (MT == 2) { DSM_LAUNCH_TILED(2) } else { DSM_LAUNCH_TILED(1) }
+#undef DSM_LAUNCH_TILED
   const bool rows_ok = (EPI == EPI_STORE) && a.norm_out && a.vec && !a.Y2 && a.Y && a.N <= 4096 && a.ymap.bstride == 0;
   if (chunks > 1 && !(EPI == EPI_QKV && a.defer_reduce)) {
     if (rows_ok) {
@@ -884,6 +911,58 @@ int launch_gemm_t(dsm_engine* e, hipStream_t st, GemmArgs& a, bool aligned) {
                        a.N, a.norm_eps, a.norm_rms);
     HIPCHK(hipGetLastError());
   }
+  return 0;
+}
+
+// Run `body` (a sequence of launches on `st`) eagerly, or — once it has run twice with the same key — capture it into a
+// hipGraph and replay that from then on.  key: everything the body's launch arguments depend on that may change between
+// calls (caller-supplied pointers, branch selectors).
+template <typename F>
+int run_captured(dsm_engine* e, dsm_engine::GraphSlot& gs, hipStream_t st, uint64_t key, F&& body) {
+  if (!e->use_graphs || e->prof_mask != 0 || gs.disabled) { e->eager_bodies += 1; return body(); }
+  if (gs.exec && gs.key == key && gs.ws_gen == e->ws_gen) {
+    HIPCHK(hipGraphLaunch(gs.exec, st));
+    e->graph_launches += 1;
+    return 0;
+  }
+  if (gs.key != key || gs.ws_gen != e->ws_gen) {  // new arguments: settle again before capturing
+    gs.key = key;
+    gs.ws_gen = e->ws_gen;
+    gs.warm = 0;
+    if (gs.exec) { (void)hipGraphExecDestroy(gs.exec); gs.exec = nullptr; }
+  }
+  if (gs.warm < 2) {
+    gs.warm += 1;
+    e->eager_bodies += 1;
+    const int rc = body();
+    if (gs.ws_gen != e->ws_gen) { gs.ws_gen = e->ws_gen; gs.warm = 0; }  // a workspace moved during this run
+    return rc;
+  }
+  HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+  e->capturing = true;
+  e->capture_failed = false;
+  const int rc = body();
+  e->capturing = false;
+  hipGraph_t g = nullptr;
+  const hipError_t he = hipStreamEndCapture(st, &g);
+  if (rc || he != hipSuccess || !g) {
+    if (g) (void)hipGraphDestroy(g);
+    (void)hipGetLastError();
+    gs.disabled = true;  // this body does not capture here: stay eager from now on
+    e->eager_bodies += 1;
+    return body();
+  }
+  const hipError_t hi = hipGraphInstantiate(&gs.exec, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (hi != hipSuccess) {
+    gs.exec = nullptr;
+    gs.disabled = true;
+    (void)hipGetLastError();
+    e->eager_bodies += 1;
+    return body();
+  }
+  HIPCHK(hipGraphLaunch(gs.exec, st));
+  e->graph_launches += 1;
   return 0;
 }
 

@@ -495,6 +495,126 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs a) {
   }
 }
 
+// ---- tiled GEMM, whole K inside the workgroup (large batches: the (n, m) tiles alone fill the chip, so there is no
+// split-K across workgroups, no slabs, no reduce launch).  Same tile, same LDS staging, same canonical order as
+// gemm_tile_kernel — chunk sums of 256 k are formed in `acc` and added left to right into `tot` — but the loads run as a
+// ROLLING window over the 32-wide blocks of the whole K range: four register slots hold blocks g .. g+3, and as soon
+// as block g has been consumed its slot requests block g+4, across chunk boundaries.  (The r01 chunk loop inside
+// gemm_tile_kernel requested a whole chunk only after finishing the previous one: every 8 blocks the MFMA pipe of the
+// wave drained behind an L2 / HBM round trip — 64 % of the f32-MFMA rate at B >= 512.)
+// Named scalars and a hand-unrolled body, not arrays: see gemm_tile_kernel.  Window depth D: 4 blocks, or 2 where a
+// block is twice the MFMA work (the gate's two n-tiles per wave) or twice the registers (f32 weights) — the same ~4096
+// MFMA cycles of cover, and the four-slot form of those two spilled.
+template <typename WT, int NT>
+struct LoopDepth {
+  static constexpr int MAX = (NT == 2 || sizeof(WT) == 4) ? 2 : 4;
+};
+template <typename WT, typename KVT, int MT, int NT, int EPI, int D>
+__global__ __launch_bounds__(256, 2) void gemm_loop_kernel(GemmArgs a) {
+  static_assert(D == 2 || D == 4, "window depth");
+  __shared__ __attribute__((aligned(16))) float Xs[2][16 * MT][DSM_XS_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int m_base = blockIdx.z * (16 * MT);
+  const int n_base = blockIdx.x * 64 + 16 * wave;
+  const WT* W = reinterpret_cast<const WT*>(a.W);
+  const WT* wrow[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) wrow[nt] = W + (long)(n_base + nt * a.nt_stride + r) * a.Kpad + 8 * q;
+  constexpr int PIECES = 16 * MT * 8;
+  constexpr bool TWO = PIECES > 256;
+  const bool has0 = tid < PIECES;
+  const int row0 = has0 ? (tid >> 3) : 0, part = tid & 7;
+  int m0 = m_base + row0;
+  m0 = m0 < a.M ? m0 : a.M - 1;
+  const float* xsrc0 = a.X + a.xmap.off(m0) + 4 * part;
+  const int xdst0 = row0 * DSM_XS_LD + 4 * part;
+  int m1 = m_base + row0 + 32;
+  m1 = m1 < a.M ? m1 : a.M - 1;
+  const float* xsrc1 = a.X + a.xmap.off(m1) + 4 * part;
+  const int xdst1 = (row0 + 32) * DSM_XS_LD + 4 * part;
+  const int nb = a.Kpad >> 5;  // 32-wide blocks of the whole reduction
+
+  f32x4 acc[NT][MT], tot[NT][MT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      tot[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  float4 xp0, xp1, xp2, xp3, xq0, xq1, xq2, xq3;
+  Raw8<WT> rw0[NT], rw1[NT], rw2[NT], rw3[NT];
+  // block indices are clamped to the last block (loaded again, never used): no branch around any load
+#define DSM_LLOAD(S, G)                                                              \
+  {                                                                                  \
+    const int kb_ = 32 * min((G), nb - 1);                                           \
+    xp##S = *reinterpret_cast<const float4*>(xsrc0 + kb_);                           \
+    xq##S = TWO ? *reinterpret_cast<const float4*>(xsrc1 + kb_) : xp##S;             \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) rw##S[nt].load(wrow[nt] + kb_); \
+  }
+  DSM_LLOAD(0, 0) DSM_LLOAD(1, 1)
+  if (D == 4) { DSM_LLOAD(2, 2) DSM_LLOAD(3, 3) }
+  __builtin_amdgcn_sched_barrier(0);
+#define DSM_LSTEP(S)                                                                 \
+  {                                                                                  \
+    const int gb = g + (S);                                                          \
+    float wa[NT][8], xb[MT][8];                                                      \
+    if (gb < nb) { /* workgroup-uniform */                                           \
+      float* xs = &Xs[(S) & 1][0][0]; /* g % D == 0, D even: block gb uses buffer gb & 1 */ \
+      if (has0) *reinterpret_cast<float4*>(xs + xdst0) = xp##S;                      \
+      if (TWO) *reinterpret_cast<float4*>(xs + xdst1) = xq##S;                       \
+      __syncthreads();                                                               \
+      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) rw##S[nt].unpack(wa[nt]);    \
+      _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                            \
+        const float* fp = xs + (16 * mt + r) * DSM_XS_LD + 8 * q;                    \
+        const float4 f0 = *reinterpret_cast<const float4*>(fp), f1 = *reinterpret_cast<const float4*>(fp + 4); \
+        xb[mt][0] = f0.x; xb[mt][1] = f0.y; xb[mt][2] = f0.z; xb[mt][3] = f0.w;      \
+        xb[mt][4] = f1.x; xb[mt][5] = f1.y; xb[mt][6] = f1.z; xb[mt][7] = f1.w;      \
+      }                                                                              \
+    }                                                                                \
+    DSM_LLOAD(S, gb + D) /* the slot is free again: D blocks ahead, whatever chunk that is */ \
+    if (gb < nb) {                                                                   \
+      _Pragma("unroll") for (int s = 0; s < 8; ++s) {                                \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                            \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                            \
+          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nt][s], xb[mt][s], acc[nt][mt], 0, 0, 0); \
+        if (NT * MT > 1) __builtin_amdgcn_sched_barrier(0); /* round-robin over the accumulators */ \
+      }                                                                              \
+      if ((gb & 7) == 7 || gb == nb - 1) { /* a 256-wide chunk is complete: canonical left-to-right chunk sum */ \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                            \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                          \
+          tot[nt][mt] = tot[nt][mt] + acc[nt][mt]; /* first chunk: +0 + acc == acc bit for bit (acc starts at +0, so it is never -0) */ \
+          acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};                                 \
+        }                                                                            \
+      }                                                                              \
+    }                                                                                \
+  }
+#pragma clang loop unroll(disable)
+  for (int g = 0; g < nb; g += D) {
+    DSM_LSTEP(0) DSM_LSTEP(1)
+    if (D == 4) { DSM_LSTEP(2) DSM_LSTEP(3) }
+  }
+#undef DSM_LLOAD
+#undef DSM_LSTEP
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m_base + 16 * mt + r;
+    if (EPI == EPI_GATE) {
+      epi_gate(a, tot[0][mt], tot[NT - 1][mt], m, n_base + 4 * q);
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n = n_base + nt * a.nt_stride + 4 * q;
+        if (EPI == EPI_RVQ)
+          epi_rvq(a, tot[nt][mt], m, n, (n_base + nt * a.nt_stride) >> 4, q);
+        else
+          epi_store_qkv<KVT, EPI>(a, tot[nt][mt], m, n);
+      }
+    }
+  }
+}
+
 // Ordered sum of `chunks` slab values at p, p + cstride, ...: loads are issued eight at a time, the adds stay
 // strictly left to right (canonical split-K order).
 __device__ __forceinline__ f32x4 slab_sum(const float* p, long cstride, int chunks) {

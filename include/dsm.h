@@ -119,6 +119,8 @@ typedef struct dsm_metrics {
   double algorithmic_bytes_lm;
   uint64_t steps_encode;
   uint64_t steps_lm;
+  uint64_t graph_launches;   /* launch sequences replayed as one hipGraphLaunch (Mimi encode / decode, one LM stream group, one TTS step) */
+  uint64_t eager_bodies;     /* the same sequences enqueued launch by launch (warm-up runs, DSM_GRAPHS=0, profiling on) */
 } dsm_metrics;
 
 /*
@@ -275,6 +277,7 @@ int dsm_tts_audio_tokens(dsm_tts*, int slot, int step, uint32_t* out /* [num_sli
 int dsm_tts_step_idx(dsm_tts*, int slot);
 int dsm_tts_reset_slot(dsm_tts*, int slot);
 int dsm_tts_debug_read(dsm_tts*, const char* name, float* out, size_t cap); /* "lm.hidden", "lm.logits" */
+int dsm_tts_get_metrics(dsm_tts*, dsm_metrics* out); /* graph_launches / eager_bodies only */
 
 /* The LM step splits the batch into stream groups (slots [first, first+n) each on its own HIP stream) so that one
  * group's HBM-bound attention overlaps another's MFMA-bound GEMMs; results do not depend on the split.  Returns the

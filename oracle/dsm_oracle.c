@@ -18,6 +18,9 @@
 #include "dsm_oracle.h"
 
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -63,6 +66,16 @@ static int* dot_order(int K) {
         if (k < K) ord[n++] = k;
       }
   return ord;
+}
+
+/* OpenMP team size for everything below.  A GPU box shows every host core but grants a small CPU share: with small models a
+ * 16-thread team spends its time spinning at barriers (200 ms per frame instead of 8), so the medium-config tests ask for 4. */
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
 }
 
 float orc_dot(const float* x, const float* w, int K) {

@@ -38,6 +38,8 @@ int orc_mimi_reset_slot(orc_asr*, int side, int slot);
 int orc_asr_poll_msgs(orc_asr*, dsm_asr_msg* msgs, int cap, uint32_t* tokens_out, int tokens_cap);
 int orc_debug_read(orc_asr*, const char* name, float* out, size_t cap);
 
+void orc_set_num_threads(int n); /* OpenMP team size (small models: few threads) */
+
 /* ---- unit-level entry points (tests of single ops; same canonical orders) ---- */
 float orc_dot(const float* x, const float* w, int K);
 void orc_linear(float* y, int ldy, const float* x, int ldx, const float* W, int ldw, const float* bias, int M,

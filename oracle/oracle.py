@@ -38,6 +38,8 @@ def lib():
         L.orc_mimi_reset_slot.argtypes = [vp, C.c_int, C.c_int]
         L.orc_asr_poll_msgs.argtypes = [vp, C.POINTER(AsrMsg), C.c_int, vp, C.c_int]
         L.orc_debug_read.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
+        L.orc_set_num_threads.argtypes = [C.c_int]
+        L.orc_set_num_threads.restype = None
         L.orc_dot.argtypes = [vp, vp, C.c_int]
         L.orc_dot.restype = C.c_float
         L.orc_linear.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int]
@@ -93,6 +95,15 @@ def lib():
     return _lib
 
 
+def set_num_threads(n):
+    """OpenMP team size of the oracle from now on (small models step faster with few threads on a shared box)."""
+    lib().orc_set_num_threads(int(n))
+
+
+def default_num_threads():
+    return int(os.environ.get("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1))))
+
+
 def p(a):
     if a is None:
         return None
@@ -106,6 +117,8 @@ class OracleAsr:
     def __init__(self, cfg, batch_size, lm_path, mimi_path):
         self.L = lib()
         self.cfg, self.B = cfg, batch_size
+        # small models: a big OpenMP team only spins at barriers (on a GPU box with a small CPU share, 25x slower)
+        set_num_threads(4 if cfg.lm.d_model <= 512 else default_num_threads())
         err = C.create_string_buffer(512)
         self.h = self.L.orc_asr_create(C.byref(cfg), batch_size, lm_path.encode(), mimi_path.encode(), err, 512)
         if not self.h:
@@ -186,6 +199,7 @@ class OracleTts:
     def __init__(self, cfg, batch_size, lm_path):
         self.L = lib()
         self.cfg, self.B, self.S = cfg, batch_size, cfg.dep_num_slices
+        set_num_threads(4 if cfg.lm.d_model <= 512 else default_num_threads())
         err = C.create_string_buffer(512)
         self.h = self.L.orc_tts_create(C.byref(cfg), batch_size, lm_path.encode(), err, 512)
         if not self.h:

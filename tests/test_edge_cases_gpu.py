@@ -154,3 +154,22 @@ def test_in_workgroup_chunk_loop_on_tiny_shapes(gpu, dsm, lib, orc, tiny_weights
         assert np.array_equal(lg_e[act].view(np.uint32), lg_o[act].view(np.uint32))
     eng.close()
     ora.close()
+
+
+@pytest.mark.parametrize("depth", ["4", "2"])
+def test_whole_k_loop_kernel_on_small_models(gpu, dsm, lib, orc, tiny_weights, monkeypatch, depth):
+    """DSM_CHUNK_LOOP_MIN=1 sends every split-K GEMM through gemm_loop_kernel (whole K inside the workgroup, rolling
+    load window of 4 or 2 blocks — the large-batch path) on the tiny model and on a medium one whose gating width
+    (1408 = 5 chunks + 4 blocks) ends in a partial chunk.  Same bits as the oracle, masks and a reset included."""
+    import os
+    from dsm_amd import synth
+    from test_parity_gpu import run_pair
+    monkeypatch.setenv("DSM_CHUNK_LOOP_MIN", "1")
+    monkeypatch.setenv("DSM_LOOP_DEPTH", depth)
+    rng = np.random.default_rng(2)
+    masks = (rng.random((14, 4)) < 0.8).astype(np.uint8)
+    masks[:, 0] = 1
+    run_pair(dsm, orc, dsm.config_tiny(), 4, *tiny_weights, steps=14, mask_fn=lambda s: masks[s], resets={6: [2]})
+    cfg = dsm.config_medium()
+    lm, mimi = synth.make_synth_weights(cfg, os.environ.get("DSM_WEIGHTS_DIR", "/tmp/dsm_weights"), tag="medium_bf16_hd128_ctx300")
+    run_pair(dsm, orc, cfg, 4, lm, mimi, steps=10, mask_fn=lambda s: masks[s], resets={6: [2]})
