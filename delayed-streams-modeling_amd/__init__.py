@@ -123,7 +123,7 @@ ABI_SYMBOLS = [
     "dsm_worker_create_with_backend", "dsm_worker_destroy", "dsm_worker_last_error", "dsm_worker_set_detokenizer", "dsm_worker_open", "dsm_worker_close",
     "dsm_worker_send", "dsm_worker_step", "dsm_worker_recv", "dsm_worker_buffered",
     "dsm_tts_config_v202501", "dsm_tts_create", "dsm_tts_destroy", "dsm_tts_last_error", "dsm_tts_step",
-    "dsm_tts_audio_tokens", "dsm_tts_step_idx", "dsm_tts_reset_slot", "dsm_tts_debug_read", "dsm_tts_get_metrics",
+    "dsm_tts_audio_tokens", "dsm_tts_step_idx", "dsm_tts_reset_slot", "dsm_tts_debug_read", "dsm_tts_get_metrics", "dsm_tts_set_sampling",
 ]
 PROF_TAGS = ["attn_lm", "gemm_lm", "attn_mimi", "gemm_mimi", "rvq", "other"]
 
@@ -234,6 +234,7 @@ def load_library(path=None):
     lib.dsm_tts_reset_slot.argtypes = [vp, C.c_int]
     lib.dsm_tts_debug_read.argtypes = [vp, C.c_char_p, fp, C.c_size_t]
     lib.dsm_tts_get_metrics.argtypes = [vp, C.POINTER(Metrics)]
+    lib.dsm_tts_set_sampling.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_uint64]
     for name in ("dsm_tts_create", "dsm_tts_step", "dsm_tts_audio_tokens", "dsm_tts_step_idx", "dsm_tts_reset_slot",
                  "dsm_tts_debug_read"):
         getattr(lib, name).restype = C.c_int
@@ -598,7 +599,9 @@ class AsrEngine:
         self._check(self.lib.dsm_mimi_decode_step_dev(self.h, d_codes, d_mask, d_pcm))
 
     def step_tokens(self, codes, mask):
-        codes = np.ascontiguousarray(codes, dtype=np.uint32).reshape(self.B, self.n_q)
+        """codes None: use the device-resident codes of the last encode_step (srv/batched_asr.rs hands them over on-device too)."""
+        if codes is not None:
+            codes = np.ascontiguousarray(codes, dtype=np.uint32).reshape(self.B, self.n_q)
         mask = np.ascontiguousarray(mask, dtype=np.uint8).reshape(self.B)
         text = np.zeros(self.B, dtype=np.uint32)
         nh = self.cfg.extra_heads_num
@@ -756,3 +759,7 @@ class TtsEngine:
         m = Metrics()
         self._check(self.lib.dsm_tts_get_metrics(self.h, C.byref(m)))
         return m
+
+    def set_sampling(self, slot, top_k, temperature, seed):
+        """Sampling::TopK{k, temperature} seeded with `seed` for the slot's text and audio processors (srv/tts.rs:401-415)."""
+        self._check(self.lib.dsm_tts_set_sampling(self.h, slot, top_k, temperature, seed))

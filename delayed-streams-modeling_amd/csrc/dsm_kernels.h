@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "dsm_numerics.h"
+#include "dsm_sampling.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -1165,18 +1166,88 @@ __global__ void tts_input_kernel(float* __restrict__ x, const uint16_t* __restri
   }
 }
 
-// text-token rule of State::step (:178-197).  allowed >= 0: Text(v); -1: Pad; -2: PadOrEpad (argmax of the text
-// logits decides pad vs end-of-pad unless force_eop, i.e. consecutive_pads > max_consecutive_pads)
+// Seeded top-k sampling of one row by a 256-thread block (dsm_sampling.h: LogitsProcessor with Sampling::TopK).
+// keys: LDS, vpad (power of two >= V) u64 entries; scratch: LDS, 9 floats.  Returns the token in every thread and
+// advances the slot's generator by one word.  Reductions follow the canonical block order (thread t owns j = t mod 256
+// ascending, wave butterflies, four wave totals left to right); the bitonic sort orders unique keys, so its network
+// shape does not matter.
+struct SampleArgs {
+  const int32_t* top_k;   // [B]: 0 = ArgMax
+  const float* inv_t;     // [B]: (float)(1 / temperature)
+  const uint32_t* key;    // [B][8] ChaCha key
+  uint32_t* pos;          // [B] words drawn so far from this processor's stream
+  int vpad;
+};
+__device__ inline uint32_t block_sample_topk(const float* __restrict__ lg, int V, int k, float invT,
+                                             const uint32_t* __restrict__ key, uint32_t* __restrict__ pos, int vpad,
+                                             uint64_t* keys, float* scratch) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float m = -DSM_INF_F;
+  for (int j = tid; j < V; j += 256) m = fmaxf(m, lg[j] * invT);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if (lane == 0) scratch[wave] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3]));
+  float tp = 0.0f;
+  for (int j = tid; j < V; j += 256) {
+    const float e = dsm_expf(lg[j] * invT - m);
+    keys[j] = (uint64_t)__float_as_uint(e);
+    tp = tp + e;
+  }
+  tp = wave_sum64(tp);
+  if (lane == 0) scratch[4 + wave] = tp;
+  __syncthreads();
+  const float sum = ((scratch[4] + scratch[5]) + scratch[6]) + scratch[7];
+  for (int j = tid; j < vpad; j += 256)
+    keys[j] = j < V ? dsm_sample_key(__uint_as_float((uint32_t)keys[j]) / sum, (uint32_t)j) : 0ull;
+  __syncthreads();
+  if (k < V) {  // bitonic sort, descending
+    for (int size = 2; size <= vpad; size <<= 1)
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        for (int i = tid; i < (vpad >> 1); i += 256) {
+          const int lo = 2 * i - (i & (stride - 1));
+          const int hi = lo + stride;
+          const bool desc = (lo & size) == 0;
+          const uint64_t a = keys[lo], b = keys[hi];
+          if ((a < b) == desc) { keys[lo] = b; keys[hi] = a; }
+        }
+        __syncthreads();
+      }
+  }
+  if (tid == 0) {
+    const uint32_t u = dsm_chacha_word(key, (uint64_t)*pos, 12);
+    *pos = *pos + 1u;
+    scratch[8] = __uint_as_float(dsm_weighted_draw(keys, k < V ? k : V, u));
+  }
+  __syncthreads();
+  const uint32_t tok = __float_as_uint(scratch[8]);
+  __syncthreads();
+  return tok;
+}
+
+// text-token rule of State::step (:178-197).  allowed >= 0: Text(v); -1: Pad; -2: PadOrEpad (text_lp.sample of the text
+// logits — argmax, or seeded top-k for slots configured with dsm_tts_set_sampling — decides pad vs end-of-pad unless
+// force_eop, i.e. consecutive_pads > max_consecutive_pads)
 __global__ void tts_text_token_kernel(const float* __restrict__ logits, int V, const int32_t* __restrict__ allowed,
                                       const uint8_t* __restrict__ force_eop, uint32_t pad, uint32_t eop,
-                                      uint32_t* __restrict__ text_token, uint32_t* __restrict__ last_tok) {
+                                      uint32_t* __restrict__ text_token, uint32_t* __restrict__ last_tok, SampleArgs sa) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int b = blockIdx.x;
   const int32_t al = allowed[b];
   uint32_t tok;
   if (al >= 0) tok = (uint32_t)al;
   else if (al == -1) tok = pad;
   else if (force_eop[b]) tok = eop;
-  else tok = ((uint32_t)block_argmax_first(logits + (long)b * V, V) == pad) ? pad : eop;  // block-uniform branch
+  else {  // block-uniform branch
+    uint32_t sampled;
+    if (sa.top_k && sa.top_k[b] > 0)
+      sampled = block_sample_topk(logits + (long)b * V, V, sa.top_k[b], sa.inv_t[b], sa.key + 8 * b, sa.pos + b, sa.vpad,
+                                  reinterpret_cast<uint64_t*>(smem), reinterpret_cast<float*>(smem + 8 * (size_t)sa.vpad));
+    else
+      sampled = (uint32_t)block_argmax_first(logits + (long)b * V, V);
+    tok = (sampled == pad) ? pad : eop;
+  }
   if (threadIdx.x == 0) {
     text_token[b] = tok;
     last_tok[b] = tok;
@@ -1194,13 +1265,20 @@ __global__ void dep_gather_kernel(float* __restrict__ e, const float* __restrict
   for (int j = threadIdx.x; j < D / 4; j += blockDim.x) dst[j] = src[j];
 }
 
-// DepFormer::sample slice epilogue: ArgMax sample, forced pre-delay pad for the NEXT slice's input (:671-680)
+// DepFormer::sample slice epilogue: lp.sample (ArgMax, or seeded top-k per slot), forced pre-delay pad for the NEXT
+// slice's input (:671-680)
 __global__ void dep_argmax_kernel(const float* __restrict__ logits, int V, int k, int S, uint32_t* __restrict__ lat,
                                   uint32_t* __restrict__ last_tok, const uint8_t* __restrict__ run,
-                                  const uint8_t* __restrict__ forced, uint32_t pad) {
+                                  const uint8_t* __restrict__ forced, uint32_t pad, SampleArgs sa) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int b = blockIdx.x;
   if (!run[b]) return;
-  const uint32_t tok = (uint32_t)block_argmax_first(logits + (long)b * V, V);
+  uint32_t tok;
+  if (sa.top_k && sa.top_k[b] > 0)
+    tok = block_sample_topk(logits + (long)b * V, V, sa.top_k[b], sa.inv_t[b], sa.key + 8 * b, sa.pos + b, sa.vpad,
+                            reinterpret_cast<uint64_t*>(smem), reinterpret_cast<float*>(smem + 8 * (size_t)sa.vpad));
+  else
+    tok = (uint32_t)block_argmax_first(logits + (long)b * V, V);
   if (threadIdx.x == 0) {
     lat[(long)b * S + k] = tok;
     last_tok[b] = (forced[b] && k > 0) ? pad : tok;

@@ -241,8 +241,8 @@ int dsm_prof_read_device(dsm_engine*, double* total_us /*[DSM_PROF_NTAGS]*/, uin
 
 /* ------------------------------------------------------------------------------------------------
  * TTS (BASELINE.json configs[4]): tts_streaming::State::step + LmModel::forward_cond + DepFormer::sample
- * (core/tts_streaming.rs:117-242, core/lm.rs:957-1008, :640-684), greedy sampling only — the reference
- * selects Sampling::ArgMax when temperature <= 0 (srv/tts.rs:402).  The reference serves one generation at a
+ * (core/tts_streaming.rs:117-242, core/lm.rs:957-1008, :640-684); Sampling::ArgMax by default (what the reference
+ * selects when temperature <= 0, srv/tts.rs:402), seeded top-k per slot with dsm_tts_set_sampling.  The reference serves one generation at a
  * time behind a mutex (srv/tts.rs:374); here B independent generations advance together, each slot with its
  * own step index (batching the TTS path is new capability).
  * ------------------------------------------------------------------------------------------------ */
@@ -276,6 +276,13 @@ int dsm_tts_step(dsm_tts*, const uint32_t* prev_text_token, const int32_t* allow
 int dsm_tts_audio_tokens(dsm_tts*, int slot, int step, uint32_t* out /* [num_slices] */);
 int dsm_tts_step_idx(dsm_tts*, int slot);
 int dsm_tts_reset_slot(dsm_tts*, int slot);
+/* The slot's text and audio LogitsProcessor (srv/tts.rs:401-415): Sampling::TopK{k, temperature} seeded with `seed` when
+ * temperature > 0 and top_k > 1, Sampling::ArgMax otherwise (the default after create and after dsm_tts_reset_slot).
+ * Softmax over the whole vocabulary at the temperature, the k most probable tokens (probability descending, token id
+ * ascending), one weighted draw from a ChaCha12 stream (rand 0.9 StdRng, seed_from_u64): csrc/dsm_sampling.h.  The
+ * reference's order among the k survivors is an implementation detail of Rust's select_nth_unstable_by and no vector of
+ * candle's / rand's exists offline: sampled tokens are pinned engine-vs-oracle only ("parity unpinned" vs Candle). */
+int dsm_tts_set_sampling(dsm_tts*, int slot, int top_k, float temperature, uint64_t seed);
 int dsm_tts_debug_read(dsm_tts*, const char* name, float* out, size_t cap); /* "lm.hidden", "lm.logits" */
 int dsm_tts_get_metrics(dsm_tts*, dsm_metrics* out); /* graph_launches / eager_bodies only */
 

@@ -26,6 +26,7 @@
 #include <string.h>
 
 #include "../delayed-streams-modeling_amd/csrc/dsm_numerics.h"
+#include "../delayed-streams-modeling_amd/csrc/dsm_sampling.h"
 #include "../delayed-streams-modeling_amd/csrc/dsm_safetensors.h"
 
 #define ORC_NEG_INF (-INFINITY)
@@ -77,6 +78,11 @@ void orc_set_num_threads(int n) {
   (void)n;
 #endif
 }
+
+/* unit-level access to csrc/dsm_sampling.h for tests/test_sampling_cpu.py */
+uint32_t orc_chacha_word(const uint32_t* key, uint64_t index, int rounds) { return dsm_chacha_word(key, index, rounds); }
+void orc_seed_from_u64(uint64_t seed, uint32_t* key) { dsm_seed_from_u64(seed, key); }
+float orc_uniform_f32(uint32_t u, float total) { return dsm_uniform_f32(u, total); }
 
 float orc_dot(const float* x, const float* w, int K) {
   float total = 0.0f;

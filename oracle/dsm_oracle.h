@@ -113,6 +113,11 @@ int orc_tts_step(orc_tts*, const uint32_t* prev_text_token, const int32_t* allow
 int orc_tts_audio_tokens(orc_tts*, int slot, int step, uint32_t* out);
 int orc_tts_step_idx(orc_tts*, int slot);
 int orc_tts_reset_slot(orc_tts*, int slot);
+int orc_tts_set_sampling(orc_tts*, int slot, int top_k, float temperature, uint64_t seed);
+uint32_t orc_sample_topk(const float* logits, int V, int k, float inv_t, const uint32_t* key, uint32_t* pos);
+uint32_t orc_chacha_word(const uint32_t* key, uint64_t index, int rounds);
+void orc_seed_from_u64(uint64_t seed, uint32_t* key);
+float orc_uniform_f32(uint32_t u, float total);
 int orc_tts_debug_read(orc_tts*, const char* name, float* out, size_t cap);
 #ifdef __cplusplus
 }

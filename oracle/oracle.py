@@ -91,6 +91,15 @@ def lib():
         L.orc_tts_step_idx.argtypes = [vp, C.c_int]
         L.orc_tts_reset_slot.argtypes = [vp, C.c_int]
         L.orc_tts_debug_read.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
+        L.orc_tts_set_sampling.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_uint64]
+        L.orc_sample_topk.argtypes = [vp, C.c_int, C.c_int, C.c_float, vp, vp]
+        L.orc_sample_topk.restype = C.c_uint32
+        L.orc_chacha_word.argtypes = [vp, C.c_uint64, C.c_int]
+        L.orc_chacha_word.restype = C.c_uint32
+        L.orc_seed_from_u64.argtypes = [C.c_uint64, vp]
+        L.orc_seed_from_u64.restype = None
+        L.orc_uniform_f32.argtypes = [C.c_uint32, C.c_float]
+        L.orc_uniform_f32.restype = C.c_float
         _lib = L
     return _lib
 
@@ -237,6 +246,9 @@ class OracleTts:
 
     def reset_batch_idx(self, slot):
         self.L.orc_tts_reset_slot(self.h, slot)
+
+    def set_sampling(self, slot, top_k, temperature, seed):
+        self.L.orc_tts_set_sampling(self.h, slot, top_k, temperature, seed)
 
     def debug_read(self, name, n):
         out = np.zeros(n, dtype=np.float32)

@@ -138,3 +138,41 @@ def test_tts_engine_creation_is_race_free(gpu, dsm, lib, orc, tts):
             act = mask.astype(bool)
             assert np.array_equal(te[act], want[s][0][act]) and np.array_equal(ae[act], want[s][1][act]), (trial, s)
         eng.close()
+
+
+def test_tts_seeded_topk_sampling_matches_the_oracle(gpu, dsm, lib, orc, tts):
+    """DepFormer::sample / text_lp.sample with Sampling::TopK (core/lm.rs:674, core/tts_streaming.rs:188, srv/tts.rs:401-415):
+    per-slot k, temperature and seed; the device sampler (softmax at the temperature, bitonic top-k, ChaCha12 draw) must
+    pick the oracle's token at every slice of every step — slot 0 stays ArgMax, slot 1 samples from 5, slot 2 from the whole
+    vocabulary (k >= V: candle's multinomial over all tokens in id order), slot 3 from 17 with a mid-run reset (back to
+    ArgMax) and re-configuration.  Hundreds of draws per slot; parity vs Candle itself is unpinned (no reference vector)."""
+    cfg, path = tts
+    B, steps = 4, 16
+    eng, ora = dsm.TtsEngine(cfg, B, path), orc.OracleTts(cfg, B, path)
+    conf = {1: (5, 0.8, 1234), 2: (250, 1.3, 99), 3: (17, 1.0, 2**40 + 3)}
+    for e in (eng, ora):
+        for slot, (k, temp, seed) in conf.items():
+            e.set_sampling(slot, k, temp, seed)
+    greedy = orc.OracleTts(cfg, B, path)
+    differs = False
+    for s, (prev, allowed, mask) in enumerate(schedule(cfg, B, steps)):
+        if s == 9:
+            for e in (eng, ora, greedy):
+                e.reset_batch_idx(3)
+        if s == 11:
+            eng.set_sampling(3, 9, 0.7, 5)
+            ora.set_sampling(3, 9, 0.7, 5)
+        mask = np.ones(B, dtype=np.uint8) if s < 4 else mask
+        act = mask.astype(bool)
+        te, ae = eng.step(prev, allowed, mask)
+        to, ao = ora.step(prev, allowed, mask)
+        tg, ag = greedy.step(prev, allowed, mask)
+        assert np.array_equal(te[act], to[act]), f"text tokens differ at step {s}"
+        assert np.array_equal(ae[act], ao[act]), f"sampled depformer tokens differ at step {s}"
+        assert np.array_equal(ae[0], ag[0]) or not act[0]
+        differs = differs or (act[1] and not np.array_equal(ao[1], ag[1]))
+    assert differs, "sampling never changed a token: the test would prove nothing"
+    for b in range(B):
+        for i in range(eng.step_idx(b)):
+            assert np.array_equal(eng.audio_tokens(b, i), ora.audio_tokens(b, i))
+    eng.close(); ora.close(); greedy.close()
