@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--capacity-legs", default="400,2048",
                     help="comma-separated larger batches timed after the headline run (N = 1 only; '' to skip)")
+    ap.add_argument("--part", default="all", choices=["all", "lm", "enc"],
+                    help="experiment: time only the LM step (codes fed from a fixed device buffer) or only the Mimi encode")
     ap.add_argument("--spawn-check", action="store_true",
                     help="CPU rehearsal of the multi-rank control path (gloo): no engine, no GPU")
     ap.add_argument("--weights-dir", default=os.environ.get("DSM_WEIGHTS_DIR", "/tmp/dsm_weights"))
@@ -297,7 +299,11 @@ def main():
     def step():
         i = it[0]
         it[0] += 1
-        if args.no_overlap:  # everything on one stream (asr::State::step_pcm)
+        if args.part == "lm":
+            eng.step_tokens_dev(codes.data_ptr(), mask.data_ptr(), text.data_ptr(), prs.data_ptr())
+        elif args.part == "enc":
+            eng.encode_step_dev(pcm[i % n_pcm].data_ptr(), mask.data_ptr(), codes.data_ptr())
+        elif args.no_overlap:  # everything on one stream (asr::State::step_pcm)
             eng.step_pcm_dev(pcm[i % n_pcm].data_ptr(), mask.data_ptr(), codes.data_ptr(), text.data_ptr(), prs.data_ptr())
         else:
             # the reference's two-thread pipeline (srv/batched_asr.rs:314-522): Mimi encode on the encoder stream, LM
