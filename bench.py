@@ -411,10 +411,10 @@ def main():
         # kernel trace reports; the HIP-event bracket on the launching stream is kept beside it: with three streams in
         # flight it also contains the time the launch queues behind the other streams' kernels
         attn_us, attn_n = prof_dev["attn_lm"]
-        attn_avg_us = attn_us / max(attn_n, 1)
+        attn_avg_us = attn_us / max(attn_n, 1) or float("nan")
         ev_us, ev_n = prof["attn_lm"]
         achieved = attn_bytes / (attn_avg_us * 1e-6) / 1e9 if attn_n else 0.0
-        iso_avg_us = iso_dev["attn_lm"][0] / max(iso_dev["attn_lm"][1], 1)
+        iso_avg_us = iso_dev["attn_lm"][0] / max(iso_dev["attn_lm"][1], 1) or float("nan")  # --part enc: no LM attention ran
         ok_legs = [b for b, v in legs.items() if "rtf" in v and v["rtf"] >= 1.0]
         out = {
             "metric": "real-time stream throughput, %s @ bs=%d per GPU (Mimi encode + LM decode per 80 ms frame)" % (args.config, B),

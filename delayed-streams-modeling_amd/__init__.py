@@ -118,7 +118,8 @@ ABI_SYMBOLS = [
     "dsm_debug_set_positions", "dsm_mimi_decode_step", "dsm_mimi_decode_step_dev",
     "dsm_lm_stream_groups", "dsm_debug_serialize_groups", "dsm_prof_read_device",
     "dsm_wav_decode", "dsm_free", "dsm_linear_resampler_new", "dsm_linear_resampler_process",
-    "dsm_linear_resampler_free",
+    "dsm_linear_resampler_free", "dsm_ogg_demux_new", "dsm_ogg_demux_free", "dsm_ogg_demux_push", "dsm_ogg_demux_next",
+    "dsm_ogg_demux_info", "dsm_worker_set_opus_decoder",
     "dsm_inmsg_encode", "dsm_outmsg_encode", "dsm_inmsg_decode", "dsm_outmsg_decode", "dsm_worker_create",
     "dsm_worker_create_with_backend", "dsm_worker_destroy", "dsm_worker_last_error", "dsm_worker_set_detokenizer", "dsm_worker_open", "dsm_worker_close",
     "dsm_worker_send", "dsm_worker_step", "dsm_worker_recv", "dsm_worker_buffered",

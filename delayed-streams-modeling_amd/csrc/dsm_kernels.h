@@ -356,9 +356,6 @@ __global__ void gemm_mfma_kernel(GemmArgs a) {
 // per block).  chunks == 1: fused epilogue.  chunks > 1: the chunk's partial tiles go to a workspace slab in
 // MFMA register layout and gemm_reduce_kernel sums the slabs left to right (canonical order) and runs the epilogue.
 #define DSM_XS_LD 36
-#ifndef DSM_TILE_ABL  // experiments/gemm_tile_ablate.hip compiles parts of the kernel out to price them (timing only)
-#define DSM_TILE_ABL 0
-#endif
 template <typename WT, typename KVT, int MT, int NT, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs a) {
   __shared__ __attribute__((aligned(16))) float Xs[2][16 * MT][DSM_XS_LD];
@@ -389,6 +386,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs a) {
 
   const int nloop = a.chunk_loop > 1 ? a.chunk_loop : 1;
   f32x4 acc[NT][MT], tot[NT][MT];
+  float xbA[MT][8], xbB[MT][8];  // activation fragments: even blocks in A, odd blocks in B
   for (int cl = 0; cl < nloop; ++cl) {
   const int chunk = a.chunk_loop > 1 ? cl : (int)blockIdx.y;
   const int k0 = chunk * DSM_KC;
@@ -398,7 +396,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs a) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // Every load of the chunk — 8 activation pieces and 8 weight fragments per thread — is requested up front, in the
+  // Every load of the chunk — 8 activation pieces and 8 weight fragments per thread — is issued up front, in the
   // order the blocks consume them and without a branch around any of them (block indices are clamped to the chunk's
   // last block; threads without an activation piece load a row they never store).  A load under a branch makes the
   // compiler wait for it on the spot, and s_waitcnt counts loads in issue order, so fetching "two blocks ahead"
@@ -412,44 +410,71 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs a) {
   Raw8<WT> rw##I[NT];                                                                  \
   {                                                                                    \
     const int kb_ = k0 + 32 * ((I) < nkb ? (I) : nkb - 1);                             \
-    if (DSM_TILE_ABL & 1) { xp##I = make_float4(1.f, 2.f, 3.f, 4.f); xq##I = xp##I; } else {                  \
     xp##I = *reinterpret_cast<const float4*>(xsrc0 + kb_);                             \
-    xq##I = TWO ? *reinterpret_cast<const float4*>(xsrc1 + kb_) : xp##I; }             \
-    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                  \
-      if (DSM_TILE_ABL & 2) rw##I[nt].load(wrow[nt]); else rw##I[nt].load(wrow[nt] + kb_); \
+    xq##I = TWO ? *reinterpret_cast<const float4*>(xsrc1 + kb_) : xp##I;               \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) rw##I[nt].load(wrow[nt] + kb_);  \
   }
   DSM_FOR8(DSM_LOADBLK)
   __builtin_amdgcn_sched_barrier(0);  // all requests issued before the first block waits for its own
-#define DSM_BLOCK(I)                                                                   \
+  // Fragments of block i+1 are read from LDS while the MFMAs of block i run (r02): a block opens with its first MFMA
+  // group right behind the barrier instead of "store, barrier, wait for the LDS read".  One barrier per block: block
+  // i+1's activations are stored before it and read after it; the buffer they overwrite was last read (as block i-1)
+  // before the previous barrier.
+#define DSM_XSTORE(I)                                                                  \
+  {                                                                                    \
+    float* xs_ = &Xs[(I) & 1][0][0];                                                   \
+    if (has0) *reinterpret_cast<float4*>(xs_ + xdst0) = xp##I;                         \
+    if (TWO) *reinterpret_cast<float4*>(xs_ + xdst1) = xq##I;                          \
+  }
+#define DSM_XFRAG(XB, I)                                                               \
+  _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                  \
+    const float* fp = &Xs[(I) & 1][0][0] + (16 * mt + r) * DSM_XS_LD + 8 * q;          \
+    const float4 f0 = *reinterpret_cast<const float4*>(fp), f1 = *reinterpret_cast<const float4*>(fp + 4); \
+    XB[mt][0] = f0.x; XB[mt][1] = f0.y; XB[mt][2] = f0.z; XB[mt][3] = f0.w;            \
+    XB[mt][4] = f1.x; XB[mt][5] = f1.y; XB[mt][6] = f1.z; XB[mt][7] = f1.w;            \
+  }
+#define DSM_XMFMA(CUR, S0, S1)                                                         \
+  _Pragma("unroll") for (int s = (S0); s < (S1); ++s) {                                \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                  \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                  \
+      acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nt][s], CUR[mt][s], acc[nt][mt], 0, 0, 0); \
+    if (NT * MT > 1) __builtin_amdgcn_sched_barrier(0); /* round-robin over the accumulators */ \
+  }
+  // PIPE: the two-fragment-set form.  The gate's two n-tiles per wave do not have the registers for it (178 VGPRs: one
+  // workgroup per CU less; 16x4 m-tiles: spills), so NT = 2 keeps the plain order: store, barrier, read, multiply.
+  constexpr bool PIPE = NT == 1;
+  if (PIPE) {
+    if (cl > 0) __syncthreads();  // chunk loop: the previous chunk's last fragment reads are done before Xs[0] is rewritten
+    DSM_XSTORE(0)
+    __syncthreads();
+    DSM_XFRAG(xbA, 0)
+  }
+#define DSM_BLOCK(I, IN, CUR, NXT)                                                     \
   if ((I) < nkb) { /* workgroup-uniform */                                             \
-    float* xs = &Xs[(I) & 1][0][0];                                                    \
-    if (!(DSM_TILE_ABL & 4)) {                                                         \
-    if (has0) *reinterpret_cast<float4*>(xs + xdst0) = xp##I;                          \
-    if (TWO) *reinterpret_cast<float4*>(xs + xdst1) = xq##I; }                         \
-    if (!(DSM_TILE_ABL & 8)) __syncthreads();                                          \
     float wa[NT][8];                                                                   \
     _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) rw##I[nt].unpack(wa[nt]);        \
-    float xb[MT][8];                                                                   \
-    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                \
-      const float* fp = xs + (16 * mt + r) * DSM_XS_LD + 8 * q;                        \
-      float4 f0, f1;                                                                   \
-      if (DSM_TILE_ABL & 4) { f0 = xp##I; f1 = xq##I; f0.x += mt; } else {             \
-      f0 = *reinterpret_cast<const float4*>(fp); f1 = *reinterpret_cast<const float4*>(fp + 4); } \
-      xb[mt][0] = f0.x; xb[mt][1] = f0.y; xb[mt][2] = f0.z; xb[mt][3] = f0.w;          \
-      xb[mt][4] = f1.x; xb[mt][5] = f1.y; xb[mt][6] = f1.z; xb[mt][7] = f1.w;          \
-    }                                                                                  \
-    _Pragma("unroll") for (int s = 0; s < 8; ++s) {                                    \
-      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                \
-      _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                \
-        if (DSM_TILE_ABL & 16) acc[nt][mt][0] += wa[nt][s] * xb[mt][s]; else           \
-          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nt][s], xb[mt][s], acc[nt][mt], 0, 0, 0); \
-      if (NT * MT > 1) __builtin_amdgcn_sched_barrier(0); /* round-robin over the accumulators */ \
+    if (PIPE) {                                                                        \
+      if ((I) + 1 < nkb) DSM_XSTORE(IN)                                                \
+      __syncthreads();                                                                 \
+      DSM_XMFMA(CUR, 0, 1)                                                             \
+      if ((I) + 1 < nkb) { DSM_XFRAG(NXT, IN) }                                        \
+      __builtin_amdgcn_sched_barrier(0);                                               \
+      DSM_XMFMA(CUR, 1, 8)                                                             \
+    } else {                                                                           \
+      DSM_XSTORE(I)                                                                    \
+      __syncthreads();                                                                 \
+      DSM_XFRAG(xbA, I)                                                                \
+      DSM_XMFMA(xbA, 0, 8)                                                             \
     }                                                                                  \
   }
-  DSM_FOR8(DSM_BLOCK)
+  DSM_BLOCK(0, 1, xbA, xbB) DSM_BLOCK(1, 2, xbB, xbA) DSM_BLOCK(2, 3, xbA, xbB) DSM_BLOCK(3, 4, xbB, xbA)
+  DSM_BLOCK(4, 5, xbA, xbB) DSM_BLOCK(5, 6, xbB, xbA) DSM_BLOCK(6, 7, xbA, xbB) DSM_BLOCK(7, 7, xbB, xbA)
 #undef DSM_FOR8
 #undef DSM_LOADBLK
 #undef DSM_BLOCK
+#undef DSM_XSTORE
+#undef DSM_XFRAG
+#undef DSM_XMFMA
   // canonical split-K order: chunk sums added left to right (here in registers, otherwise by the reduce kernels)
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)
@@ -461,7 +486,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs a) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = tot[nt][mt];
 
-  if ((DSM_TILE_ABL & 32) && acc[0][0][0] != 1234.5f) return;
   if (chunks > 1) {
     // slab[chunk][m][n] f32, row-major with ld = ws_ntiles*16: a lane stores its 4 consecutive n of row m
     const long ld = (long)a.ws_ntiles * 16;
@@ -557,31 +581,55 @@ __global__ __launch_bounds__(256, 2) void gemm_loop_kernel(GemmArgs a) {
   DSM_LLOAD(0, 0) DSM_LLOAD(1, 1)
   if (D == 4) { DSM_LLOAD(2, 2) DSM_LLOAD(3, 3) }
   __builtin_amdgcn_sched_barrier(0);
-#define DSM_LSTEP(S)                                                                 \
+  // The activation fragments of block g+1 are fetched from LDS while the MFMAs of block g run (two register sets, A for even
+  // blocks, B for odd ones): a block no longer opens with "store to LDS, barrier, wait for the LDS read" in front of its
+  // first MFMA — with two waves per SIMD running the same program those gaps line up and idle the matrix pipe (PMC: 64 %
+  // MFMA-busy at M = 512 before, profiles/r02).  One barrier per block remains; what it orders: block g+1's activations
+  // are stored before it and read after it, and the buffer they overwrite was last read (as block g-1) before the
+  // previous barrier.
+  float xbA[MT][8], xbB[MT][8];
+#define DSM_LSTORE(S, BUF)                                                           \
+  {                                                                                  \
+    float* xs_ = &Xs[BUF][0][0];                                                     \
+    if (has0) *reinterpret_cast<float4*>(xs_ + xdst0) = xp##S;                       \
+    if (TWO) *reinterpret_cast<float4*>(xs_ + xdst1) = xq##S;                        \
+  }
+#define DSM_LFRAG(XB, BUF)                                                           \
+  _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                \
+    const float* fp = &Xs[BUF][0][0] + (16 * mt + r) * DSM_XS_LD + 8 * q;            \
+    const float4 f0 = *reinterpret_cast<const float4*>(fp), f1 = *reinterpret_cast<const float4*>(fp + 4); \
+    XB[mt][0] = f0.x; XB[mt][1] = f0.y; XB[mt][2] = f0.z; XB[mt][3] = f0.w;          \
+    XB[mt][4] = f1.x; XB[mt][5] = f1.y; XB[mt][6] = f1.z; XB[mt][7] = f1.w;          \
+  }
+  DSM_LSTORE(0, 0)
+  __syncthreads();
+  DSM_LFRAG(xbA, 0)
+  // S: this block's slot, SN: the next block's slot, CUR / NXT: fragment sets (g % D == 0 and D is even: block parity == S parity)
+#define DSM_LMFMA(CUR, S0, S1)                                                       \
+  _Pragma("unroll") for (int s = (S0); s < (S1); ++s) {                              \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                \
+      acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nt][s], CUR[mt][s], acc[nt][mt], 0, 0, 0); \
+    if (NT * MT > 1) __builtin_amdgcn_sched_barrier(0); /* round-robin over the accumulators */ \
+  }
+#define DSM_LSTEP(S, SN, CUR, NXT)                                                   \
   {                                                                                  \
     const int gb = g + (S);                                                          \
-    float wa[NT][8], xb[MT][8];                                                      \
+    float wa[NT][8];                                                                 \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) rw##S[nt].unpack(wa[nt]);      \
     if (gb < nb) { /* workgroup-uniform */                                           \
-      float* xs = &Xs[(S) & 1][0][0]; /* g % D == 0, D even: block gb uses buffer gb & 1 */ \
-      if (has0) *reinterpret_cast<float4*>(xs + xdst0) = xp##S;                      \
-      if (TWO) *reinterpret_cast<float4*>(xs + xdst1) = xq##S;                       \
+      if (gb + 1 < nb) DSM_LSTORE(SN, ((S) + 1) & 1)                                 \
       __syncthreads();                                                               \
-      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) rw##S[nt].unpack(wa[nt]);    \
-      _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                            \
-        const float* fp = xs + (16 * mt + r) * DSM_XS_LD + 8 * q;                    \
-        const float4 f0 = *reinterpret_cast<const float4*>(fp), f1 = *reinterpret_cast<const float4*>(fp + 4); \
-        xb[mt][0] = f0.x; xb[mt][1] = f0.y; xb[mt][2] = f0.z; xb[mt][3] = f0.w;      \
-        xb[mt][4] = f1.x; xb[mt][5] = f1.y; xb[mt][6] = f1.z; xb[mt][7] = f1.w;      \
-      }                                                                              \
+      /* the first MFMA group goes out right behind the barrier; the LDS reads of the NEXT block's fragments follow it   \
+         (issued in front, the compiler makes every MFMA of this block wait for them) */ \
+      DSM_LMFMA(CUR, 0, 1)                                                           \
+      if (gb + 1 < nb) { DSM_LFRAG(NXT, ((S) + 1) & 1) }                             \
+      __builtin_amdgcn_sched_barrier(0);                                             \
     }                                                                                \
     DSM_LLOAD(S, gb + D) /* the slot is free again: D blocks ahead, whatever chunk that is */ \
+    __builtin_amdgcn_sched_barrier(0);                                               \
     if (gb < nb) {                                                                   \
-      _Pragma("unroll") for (int s = 0; s < 8; ++s) {                                \
-        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                            \
-        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                            \
-          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nt][s], xb[mt][s], acc[nt][mt], 0, 0, 0); \
-        if (NT * MT > 1) __builtin_amdgcn_sched_barrier(0); /* round-robin over the accumulators */ \
-      }                                                                              \
+      DSM_LMFMA(CUR, 1, 8)                                                           \
       if ((gb & 7) == 7 || gb == nb - 1) { /* a 256-wide chunk is complete: canonical left-to-right chunk sum */ \
         _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                            \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                          \
@@ -593,9 +641,15 @@ __global__ __launch_bounds__(256, 2) void gemm_loop_kernel(GemmArgs a) {
   }
 #pragma clang loop unroll(disable)
   for (int g = 0; g < nb; g += D) {
-    DSM_LSTEP(0) DSM_LSTEP(1)
-    if (D == 4) { DSM_LSTEP(2) DSM_LSTEP(3) }
+    if (D == 4) {
+      DSM_LSTEP(0, 1, xbA, xbB) DSM_LSTEP(1, 2, xbB, xbA) DSM_LSTEP(2, 3, xbA, xbB) DSM_LSTEP(3, 0, xbB, xbA)
+    } else {
+      DSM_LSTEP(0, 1, xbA, xbB) DSM_LSTEP(1, 0, xbB, xbA)
+    }
   }
+#undef DSM_LSTORE
+#undef DSM_LFRAG
+#undef DSM_LMFMA
 #undef DSM_LLOAD
 #undef DSM_LSTEP
 #pragma unroll

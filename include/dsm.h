@@ -307,10 +307,20 @@ int dsm_debug_read(dsm_engine*, const char* name, float* out, size_t cap);
  * dsm_wav_decode: channel 0 of a RIFF/WAVE body as f32 — what srv/utils.rs:263-305 `pcm_decode` hands the worker
  * (srv/batched_asr.rs:834-842) for such a body.  *pcm_out is malloc'd; release it with dsm_free.
  * dsm_linear_resampler_*: the clients' default resampler, client/rust/kyutai-client-core/src/audio.rs:133-183
- * (`LinearResampler::process_into`), streaming.  mp3 / Ogg-Opus decoding is not built.
+ * (`LinearResampler::process_into`), streaming.  mp3 and the Opus codec are not built; the Ogg container is (below).
  * ------------------------------------------------------------------------------------------------ */
 int dsm_wav_decode(const uint8_t* bytes, size_t len, float** pcm_out, size_t* n_out, int* sample_rate_out);
 void dsm_free(void*);
+/* Ogg container demultiplexer (RFC 3533 pages -> RFC 7845 Opus packets) for InMsg::OggOpus bodies, the container half of
+ * kaudio::ogg_opus::Decoder (srv/batched_asr.rs:894,941-949): streaming (bytes may be split anywhere), CRC-checked,
+ * resynchronises after damage, drops packets whose beginning or middle was lost.  No Opus codec is built here: the
+ * packets go to the decoder the host already has (dsm_worker_set_opus_decoder, or the caller's own loop). */
+typedef struct dsm_ogg_demux dsm_ogg_demux;
+dsm_ogg_demux* dsm_ogg_demux_new(void);
+void dsm_ogg_demux_free(dsm_ogg_demux*);
+int dsm_ogg_demux_push(dsm_ogg_demux*, const uint8_t* bytes, size_t len); /* -> packets waiting, or <0 */
+int dsm_ogg_demux_next(dsm_ogg_demux*, const uint8_t** packet, size_t* len, int* is_header); /* 1 / 0; pointer valid until the next call */
+int dsm_ogg_demux_info(const dsm_ogg_demux*, int* channels, int* pre_skip, uint32_t* input_rate, uint64_t* pages_ok, uint64_t* pages_bad);
 typedef struct dsm_resampler dsm_resampler;
 dsm_resampler* dsm_linear_resampler_new(uint32_t in_rate_hz, uint32_t out_rate_hz);
 size_t dsm_linear_resampler_process(dsm_resampler*, const float* in, size_t n_in, float* out, size_t out_cap);
@@ -386,6 +396,13 @@ int dsm_worker_step(dsm_worker*);
 /* Next serialised OutMsg for the slot's socket (send_loop, :960-985): 1 written, 0 none; *len = its size. */
 int dsm_worker_recv(dsm_worker*, int slot, uint8_t* buf, size_t cap, size_t* len);
 int dsm_worker_buffered(dsm_worker*, int slot);        /* samples waiting in the channel's queue (Step.buffered_pcm) */
+/* The codec half of kaudio::ogg_opus::Decoder::new(24000, FRAME_SIZE) (srv/batched_asr.rs:894): decode ONE Opus packet of
+ * the slot's stream to 24 kHz mono f32 (libopus on the host side: opus_decode_float at 24 kHz), return the sample count or
+ * <0.  With a decoder set, InMsg::OggOpus bodies are demultiplexed per channel (dsm_ogg_demux) and every audio packet is
+ * decoded and queued like InMsg::Audio (:941-947); a decode error is reported and skipped like the reference logs it.
+ * Without one, dsm_worker_send keeps refusing OggOpus messages (DSM_ERR_STATE). */
+typedef int (*dsm_opus_decode_fn)(void* user, int slot, const uint8_t* packet, size_t len, float* pcm_out, size_t cap);
+void dsm_worker_set_opus_decoder(dsm_worker*, dsm_opus_decode_fn, void* user);
 
 #ifdef __cplusplus
 }

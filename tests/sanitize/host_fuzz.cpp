@@ -4,6 +4,7 @@
 // scripted backend.  Build + run: tests/sanitize/Makefile (target `run`), wrapped by tests/test_sanitizers_cpu.py.
 // Exit code 0 = every case was either decoded or rejected cleanly; any sanitizer report aborts (-fno-sanitize-recover).
 #define DSM_HOST_ONLY 1
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -287,6 +288,91 @@ static void fuzz_wav() {
   REQUIRE(dsm_linear_resampler_new(0, 24000) == nullptr);
 }
 
+// ---- Ogg container ----
+static uint32_t ref_crc(const Bytes& b) {
+  uint32_t crc = 0;
+  for (uint8_t v : b) {
+    crc ^= (uint32_t)v << 24;
+    for (int i = 0; i < 8; ++i) crc = (crc & 0x80000000u) ? (crc << 1) ^ 0x04C11DB7u : (crc << 1);
+  }
+  return crc;
+}
+static Bytes ogg_page(uint32_t serial, uint32_t seq, uint8_t htype, const std::vector<uint8_t>& lacing, const Bytes& body) {
+  Bytes p = {'O', 'g', 'g', 'S', 0, htype, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; ++i) p.push_back((uint8_t)(serial >> (8 * i)));
+  for (int i = 0; i < 4; ++i) p.push_back((uint8_t)(seq >> (8 * i)));
+  for (int i = 0; i < 4; ++i) p.push_back(0);
+  p.push_back((uint8_t)lacing.size());
+  p.insert(p.end(), lacing.begin(), lacing.end());
+  p.insert(p.end(), body.begin(), body.end());
+  const uint32_t crc = ref_crc(p);
+  for (int i = 0; i < 4; ++i) p[22 + i] = (uint8_t)(crc >> (8 * i));
+  return p;
+}
+static void drain_ogg(dsm_ogg_demux* d) {
+  const uint8_t* pkt; size_t len; int hdr;
+  while (dsm_ogg_demux_next(d, &pkt, &len, &hdr) == 1) {
+    volatile uint8_t acc = 0;
+    for (size_t i = 0; i < len; ++i) acc = acc + pkt[i];  // touch every byte handed out
+  }
+}
+static void fuzz_ogg() {
+  Bytes stream;
+  uint32_t seq = 0;
+  {
+    Bytes head = {'O', 'p', 'u', 's', 'H', 'e', 'a', 'd', 1, 2, 56, 1, 0x80, 0xbb, 0, 0, 0, 0, 0};
+    Bytes pg = ogg_page(5, seq++, 2, {(uint8_t)head.size()}, head);
+    stream.insert(stream.end(), pg.begin(), pg.end());
+  }
+  for (int p = 0; p < 30; ++p) {  // pages of random lacing, some packets left open across pages
+    std::vector<uint8_t> lacing;
+    Bytes body;
+    const int nseg = 1 + (int)(rnd() % 40);
+    for (int i = 0; i < nseg; ++i) {
+      const uint8_t l = (rnd() % 3 == 0) ? 255 : (uint8_t)(rnd() % 255);
+      lacing.push_back(l);
+      for (int j = 0; j < l; ++j) body.push_back((uint8_t)rnd());
+    }
+    Bytes pg = ogg_page(5, seq++, (p % 4 == 3) ? 1 : 0, lacing, body);
+    stream.insert(stream.end(), pg.begin(), pg.end());
+  }
+  for (int it = 0; it < 600; ++it) {
+    Bytes b = stream;
+    const int edits = (int)(rnd() % 6);
+    for (int e = 0; e < edits; ++e) {
+      const uint32_t op = rnd() % 3;
+      const size_t at = rnd() % b.size();
+      if (op == 0) b[at] = (uint8_t)rnd();
+      else if (op == 1) b.erase(b.begin() + (long)at, b.begin() + (long)std::min(b.size(), at + rnd() % 300));
+      else b.insert(b.begin() + (long)at, (size_t)(rnd() % 50), (uint8_t)rnd());
+    }
+    dsm_ogg_demux* d = dsm_ogg_demux_new();
+    for (size_t o = 0; o < b.size();) {  // arbitrary message boundaries
+      const size_t n = std::min(b.size() - o, (size_t)(1 + rnd() % 700));
+      REQUIRE(dsm_ogg_demux_push(d, b.data() + o, n) >= 0);
+      o += n;
+      if (rnd() % 3) drain_ogg(d);
+    }
+    drain_ogg(d);
+    dsm_ogg_demux_free(d);
+    ++n_cases;
+  }
+  {  // a 4 MB flood of capture patterns and of 255-lacing pages that never close a packet: bounded memory, no output
+    dsm_ogg_demux* d = dsm_ogg_demux_new();
+    Bytes flood;
+    for (int i = 0; i < 1000000; ++i) { flood.push_back('O'); flood.push_back('g'); flood.push_back('g'); flood.push_back('S'); }
+    REQUIRE(dsm_ogg_demux_push(d, flood.data(), flood.size()) == 0);
+    std::vector<uint8_t> lacing(255, 255);
+    Bytes body(255 * 255, 0x5a);
+    for (uint32_t i = 0; i < 40; ++i) {
+      Bytes pg = ogg_page(9, i, i == 0 ? 2 : 1, lacing, body);
+      REQUIRE(dsm_ogg_demux_push(d, pg.data(), pg.size()) == 0);  // 2.6 MB of one never-ending packet: refused beyond 1 MiB
+    }
+    dsm_ogg_demux_free(d);
+    ++n_cases;
+  }
+}
+
 // ---- safetensors ----
 static void try_st(const std::string& dir, const Bytes& b) {
   const std::string path = dir + "/fuzz.safetensors";
@@ -394,6 +480,7 @@ int main(int argc, char** argv) {
   fuzz_msgpack(); lap("msgpack");
   fuzz_worker(); lap("worker");
   fuzz_wav(); lap("wav");
+  fuzz_ogg(); lap("ogg");
   fuzz_safetensors(dir); lap("safetensors");
   printf("host_fuzz ok: %ld cases, no sanitizer report\n", n_cases);
   return 0;

@@ -73,7 +73,8 @@ def test_graph_replay_equals_eager_tts(gpu, dsm, lib, monkeypatch):
     monkeypatch.delenv("DSM_GRAPHS")
     graph, g1, e1 = run()
     assert g0 == 0 and e0 == steps
-    assert g1 > 0 and g1 + e1 == steps and e1 <= 4  # two variants (with / without the depformer), two settling runs each
+    # two variants (with / without the depformer), two settling runs each, plus a re-settle when a split-K workspace still grew
+    assert g1 >= steps // 2 and g1 + e1 == steps and e1 <= 7, (g1, e1)
     sched = list(schedule(cfg, B, steps))
     for s, (a, b) in enumerate(zip(eager, graph)):
         act = np.asarray(sched[s][2]).astype(bool)
