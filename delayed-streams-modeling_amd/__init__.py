@@ -90,13 +90,16 @@ BE_RESET = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
 BE_STEP = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_float))
 BE_POLL = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(AsrMsg), C.c_int, C.POINTER(C.c_uint32), C.c_int)
 BE_ERROR = C.CFUNCTYPE(C.c_char_p, C.c_void_p)
+BE_ENCODE_ASYNC = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_int))
+BE_STEP_TICKET = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_float))
 
 
 class WorkerBackend(C.Structure):
     """dsm_worker_backend (include/dsm.h)."""
     _fields_ = [("self", C.c_void_p), ("batch_size", C.c_int), ("asr_delay_in_tokens", C.c_int),
                 ("extra_heads_num", C.c_int), ("encode_step", BE_ENCODE), ("reset_slot", BE_RESET),
-                ("step_tokens", BE_STEP), ("poll_msgs", BE_POLL), ("last_error", BE_ERROR)]
+                ("step_tokens", BE_STEP), ("poll_msgs", BE_POLL), ("last_error", BE_ERROR),
+                ("encode_async", BE_ENCODE_ASYNC), ("step_ticket", BE_STEP_TICKET)]
 
 
 class Metrics(C.Structure):
@@ -119,10 +122,11 @@ ABI_SYMBOLS = [
     "dsm_lm_stream_groups", "dsm_debug_serialize_groups", "dsm_prof_read_device",
     "dsm_wav_decode", "dsm_free", "dsm_linear_resampler_new", "dsm_linear_resampler_process",
     "dsm_linear_resampler_free", "dsm_ogg_demux_new", "dsm_ogg_demux_free", "dsm_ogg_demux_push", "dsm_ogg_demux_next",
-    "dsm_ogg_demux_info", "dsm_worker_set_opus_decoder",
+    "dsm_ogg_demux_info", "dsm_worker_set_opus_decoder", "dsm_ogg_mux_new", "dsm_ogg_mux_free", "dsm_ogg_mux_header", "dsm_ogg_mux_page",
     "dsm_inmsg_encode", "dsm_outmsg_encode", "dsm_inmsg_decode", "dsm_outmsg_decode", "dsm_worker_create",
     "dsm_worker_create_with_backend", "dsm_worker_destroy", "dsm_worker_last_error", "dsm_worker_set_detokenizer", "dsm_worker_open", "dsm_worker_close",
-    "dsm_worker_send", "dsm_worker_step", "dsm_worker_recv", "dsm_worker_buffered",
+    "dsm_worker_send", "dsm_worker_step", "dsm_worker_step_encode", "dsm_worker_step_model",
+    "dsm_mimi_encode_step_async", "dsm_asr_step_tokens_ticket", "dsm_worker_recv", "dsm_worker_buffered",
     "dsm_tts_config_v202501", "dsm_tts_create", "dsm_tts_destroy", "dsm_tts_last_error", "dsm_tts_step",
     "dsm_tts_audio_tokens", "dsm_tts_step_idx", "dsm_tts_reset_slot", "dsm_tts_debug_read", "dsm_tts_get_metrics", "dsm_tts_set_sampling",
 ]
@@ -216,10 +220,13 @@ def load_library(path=None):
     lib.dsm_worker_close.argtypes = [vp, C.c_int]
     lib.dsm_worker_send.argtypes = [vp, C.c_int, C.c_char_p, C.c_size_t]
     lib.dsm_worker_step.argtypes = [vp]
+    lib.dsm_worker_step_encode.argtypes = [vp]
+    lib.dsm_worker_step_model.argtypes = [vp]
     lib.dsm_worker_recv.argtypes = [vp, C.c_int, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.dsm_worker_buffered.argtypes = [vp, C.c_int]
     for name in ("dsm_inmsg_encode", "dsm_outmsg_encode", "dsm_inmsg_decode", "dsm_outmsg_decode", "dsm_worker_create",
-                 "dsm_worker_open", "dsm_worker_close", "dsm_worker_send", "dsm_worker_step", "dsm_worker_recv",
+                 "dsm_worker_open", "dsm_worker_close", "dsm_worker_send", "dsm_worker_step", "dsm_worker_step_encode", "dsm_worker_step_model",
+    "dsm_mimi_encode_step_async", "dsm_asr_step_tokens_ticket", "dsm_worker_recv",
                  "dsm_worker_buffered"):
         getattr(lib, name).restype = C.c_int
     lib.dsm_tts_config_v202501.argtypes = [C.POINTER(TtsConfig)]
@@ -464,6 +471,20 @@ class Worker:
 
     def step(self):
         rc = self.lib.dsm_worker_step(self.h)
+        if rc < 0:
+            raise DsmError(self._err())
+        return rc == 1
+
+    def step_encode(self):
+        """encoder_loop iteration (dsm_worker_step_encode): True if a frame was cut and queued for the model side."""
+        rc = self.lib.dsm_worker_step_encode(self.h)
+        if rc < 0:
+            raise DsmError(self._err())
+        return rc == 1
+
+    def step_model(self):
+        """model_loop + post_process for the oldest queued frame (dsm_worker_step_model)."""
+        rc = self.lib.dsm_worker_step_model(self.h)
         if rc < 0:
             raise DsmError(self._err())
         return rc == 1

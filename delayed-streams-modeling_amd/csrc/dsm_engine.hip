@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -187,6 +188,7 @@ struct dsm_engine {
   bool fuse_qkv = true;  // DSM_FUSE_QKV=0: keep the separate QKV reduce launch
   bool chunk_loop = true;  // DSM_CHUNK_LOOP=0: always split K across workgroups
   bool roll_prefetch = true;  // DSM_ROLL=0: the chunk loop requests a chunk only after finishing the previous one (r01 behaviour)
+  bool gate_occ3 = false;     // DSM_GATE_OCC3=1: the gate's whole-K kernel squeezed to 168 VGPRs (three waves per SIMD, 80 B of spills)
   int loop_depth = 4;         // DSM_LOOP_DEPTH=2: two-block rolling window (fewer registers, three waves per SIMD) where four is the default
   size_t attn_lds_pad = 60000;  // DSM_ATTN_LDS_PAD: extra dynamic LDS per attention workgroup of a large launch (2 per CU)
   int chunk_loop_min_tiles = 384;  // DSM_CHUNK_LOOP_MIN (swept at B = 512 / 1024: 384 best)
@@ -219,7 +221,7 @@ struct dsm_engine {
   static constexpr int kStreams = 1 + kMaxGroups;
   float* gemm_ws[kStreams] = {};
   size_t gemm_ws_cap[kStreams] = {};
-  uint64_t ws_gen = 0;  // bumped whenever a workspace moves: captured graphs hold the old pointer
+  std::atomic<uint64_t> ws_gen{0};  // bumped whenever a workspace moves: captured graphs hold the old pointer
   // hipGraph replay of the launch-bound inner loops: the kernel sequence of one Mimi encode / decode,
   // of one LM stream group's transformer + heads, of one TTS step is captured once its shapes, pointers and first-call
   // branches have settled (two eager runs), then replayed with ONE hipGraphLaunch — ~150 kernel nodes for ~12 us of
@@ -232,9 +234,27 @@ struct dsm_engine {
     bool disabled = false;
   };
   bool use_graphs = true;
-  bool capturing = false, capture_failed = false;
+  // capturing: per host thread (the encoder thread may capture while the model thread launches eagerly)
+  static thread_local bool capturing;
+  bool capture_failed = false;
   GraphSlot g_enc[2], g_grp[kMaxGroups], g_dec, g_tts[2];
-  uint64_t graph_launches = 0, eager_bodies = 0;
+  std::atomic<uint64_t> graph_launches{0}, eager_bodies{0};
+  // run-ahead pipeline between the encoder thread and the model thread (dsm_mimi_encode_step_async /
+  // dsm_asr_step_tokens_ticket): the reference's sync_channel(100) of PipelineMsg (srv/batched_asr.rs:291), here a ring of
+  // kPipe frames: pinned staging for the PCM + mask, a private device copy of the frame's codes, one event "encoded" and
+  // one "consumed" per entry.
+  static constexpr int kPipe = 4;
+  struct PipeSlot {
+    float* h_pcm = nullptr;
+    uint8_t* h_mask = nullptr;
+    uint32_t* d_codes = nullptr;
+    hipEvent_t ev_done = nullptr, ev_consumed = nullptr;
+    bool in_flight = false;  // encoded (or being encoded) and not yet handed to the model side
+  };
+  PipeSlot pipe[kPipe];
+  int pipe_next = 0;
+  bool pipe_ready = false;
+  std::mutex pipe_mu;
   // per-kernel-class event timing (dsm_prof_*)
   unsigned prof_mask = 0;
   // one slot per stream (0 = encoder, 1 = model): the two host threads of the worker never share a slot
@@ -361,6 +381,8 @@ struct dsm_engine {
   }
   bool skip_host_weights() const { return wmode == W_MEASURE || wmode == W_ATTACH; }
 };
+
+thread_local bool dsm_engine::capturing = false;
 
 // ----------------------------------------------------------------------------------------------
 // weight loading
@@ -842,7 +864,9 @@ int launch_gemm_tiled(dsm_engine* e, hipStream_t st, GemmArgs& a) {
   constexpr int DMAX = LoopDepth<WT, NT>::MAX;
   const bool deep = DMAX == 4 && e->loop_depth == 4;
 #define DSM_LAUNCH_TILED(MTv)                                                                                   \
-  if (roll && deep) hipLaunchKernelGGL((gemm_loop_kernel<WT, KVT, MTv, NT, EPI, DMAX>), grid, dim3(256), 0, st, a); \
+  if (roll && NT == 2 && MTv == 4 && e->gate_occ3)                                                              \
+    hipLaunchKernelGGL((gemm_loop_kernel<WT, KVT, MTv, NT, EPI, 2, 3>), grid, dim3(256), 0, st, a);            \
+  else if (roll && deep) hipLaunchKernelGGL((gemm_loop_kernel<WT, KVT, MTv, NT, EPI, DMAX>), grid, dim3(256), 0, st, a); \
   else if (roll) hipLaunchKernelGGL((gemm_loop_kernel<WT, KVT, MTv, NT, EPI, 2>), grid, dim3(256), 0, st, a);       \
   else hipLaunchKernelGGL((gemm_tile_kernel<WT, KVT, MTv, NT, EPI>), grid, dim3(256), 0, st, a);
   if (MT == 4) { DSM_LAUNCH_TILED(4) } else if (MT == 2) { DSM_LAUNCH_TILED(2) } else { DSM_LAUNCH_TILED(1) }

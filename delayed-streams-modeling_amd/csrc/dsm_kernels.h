@@ -534,8 +534,8 @@ template <typename WT, int NT>
 struct LoopDepth {
   static constexpr int MAX = (NT == 2 || sizeof(WT) == 4) ? 2 : 4;
 };
-template <typename WT, typename KVT, int MT, int NT, int EPI, int D>
-__global__ __launch_bounds__(256, 2) void gemm_loop_kernel(GemmArgs a) {
+template <typename WT, typename KVT, int MT, int NT, int EPI, int D, int OCC = 2>
+__global__ __launch_bounds__(256, OCC) void gemm_loop_kernel(GemmArgs a) {
   static_assert(D == 2 || D == 4, "window depth");
   __shared__ __attribute__((aligned(16))) float Xs[2][16 * MT][DSM_XS_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -21,10 +21,12 @@ KNOBS = [
     {"DSM_LM_GROUPS": "3"},
     {"DSM_GRAPHS": "0"},
     {"DSM_ATTN_LDS_PAD": "0"},
+    {"DSM_GATE_OCC3": "1"},
+    {"DSM_GATE_OCC3": "1", "DSM_LM_GROUPS": "4"},
 ]
 for B in Bs:
     for kn in KNOBS:
-        for k in ("DSM_ROLL", "DSM_LOOP_DEPTH", "DSM_LM_GROUPS", "DSM_GRAPHS", "DSM_ATTN_LDS_PAD"):
+        for k in ("DSM_ROLL", "DSM_LOOP_DEPTH", "DSM_LM_GROUPS", "DSM_GRAPHS", "DSM_ATTN_LDS_PAD", "DSM_GATE_OCC3"):
             os.environ.pop(k, None)
         os.environ.update(kn)
         try:

@@ -188,6 +188,15 @@ int dsm_asr_step_tokens(dsm_engine*, const uint32_t* codes, const uint8_t* mask,
 int dsm_asr_step_pcm(dsm_engine*, const float* pcm, const uint8_t* mask, uint32_t* codes_out,
                      uint32_t* text_tokens_out, float* vad_prs_out);
 
+/* The same two calls for callers that run the reference's thread pair with run-ahead (encoder_loop feeds model_loop through a
+ * bounded channel, srv/batched_asr.rs:291,314-522): dsm_mimi_encode_step_async copies the frame, enqueues upload + encode on the
+ * encoder stream and returns at once with a ticket (ring of 4 frames: DSM_ERR_STATE while all four wait for the model side);
+ * dsm_asr_step_tokens_ticket makes the model stream wait for that frame's codes (kept in a per-ticket device copy), runs the
+ * LM step and returns tokens like dsm_asr_step_tokens.  Encode of frame n+1 then overlaps the LM step of frame n on the GPU.
+ * Tickets must be consumed in the order they were issued. */
+int dsm_mimi_encode_step_async(dsm_engine*, const float* pcm, const uint8_t* mask, int* ticket);
+int dsm_asr_step_tokens_ticket(dsm_engine*, int ticket, const uint8_t* mask, uint32_t* text_tokens_out, float* vad_prs_out);
+
 /* Read the Vec<AsrMsg> the last step returned (the list lives until the next step: polling does not consume it).
  * Returns the number of messages written (<= cap; a step yields at most 2*B + 1); word tokens are copied to
  * tokens_out, truncated to tokens_cap entries — a Word whose tokens_offset + n_tokens exceeds tokens_cap was cut:
@@ -321,6 +330,16 @@ void dsm_ogg_demux_free(dsm_ogg_demux*);
 int dsm_ogg_demux_push(dsm_ogg_demux*, const uint8_t* bytes, size_t len); /* -> packets waiting, or <0 */
 int dsm_ogg_demux_next(dsm_ogg_demux*, const uint8_t** packet, size_t* len, int* is_header); /* 1 / 0; pointer valid until the next call */
 int dsm_ogg_demux_info(const dsm_ogg_demux*, int* channels, int* pre_skip, uint32_t* input_rate, uint64_t* pages_ok, uint64_t* pages_bad);
+/* Ogg multiplexer: the container half of kaudio::ogg_opus::Encoder on the TTS output side (srv/tts.rs:75-76,188-260):
+ * dsm_ogg_mux_header = `header_data()` (OpusHead page + OpusTags page), dsm_ogg_mux_page = the page `encode_page(pcm)`
+ * emits for one 80 ms frame, from the Opus packets of the host's encoder.  Both return the page bytes' count and write
+ * them when they fit in cap (a page that does not fit is not consumed: call again with a larger buffer). */
+typedef struct dsm_ogg_mux dsm_ogg_mux;
+dsm_ogg_mux* dsm_ogg_mux_new(uint32_t serial, int channels, uint32_t input_sample_rate, int pre_skip);
+void dsm_ogg_mux_free(dsm_ogg_mux*);
+int dsm_ogg_mux_header(dsm_ogg_mux*, uint8_t* out, size_t cap);
+int dsm_ogg_mux_page(dsm_ogg_mux*, const uint8_t* const* packets, const size_t* lens, int n_packets, uint64_t samples_48k,
+                     int end_of_stream, uint8_t* out, size_t cap);
 typedef struct dsm_resampler dsm_resampler;
 dsm_resampler* dsm_linear_resampler_new(uint32_t in_rate_hz, uint32_t out_rate_hz);
 size_t dsm_linear_resampler_process(dsm_resampler*, const float* in, size_t n_in, float* out, size_t out_cap);
@@ -378,6 +397,11 @@ typedef struct dsm_worker_backend {
   int (*step_tokens)(void* self, const uint8_t* mask, uint32_t* text_tokens_out /*[B]*/, float* prs_out /*[heads*B]*/);
   int (*poll_msgs)(void* self, dsm_asr_msg* msgs, int cap, uint32_t* tokens_out, int tokens_cap);
   const char* (*last_error)(void* self); /* may be NULL */
+  /* optional pair (both or neither): the run-ahead forms — encode returns at once with a ticket naming the frame's codes,
+   * the model side consumes tickets in order (dsm_mimi_encode_step_async / dsm_asr_step_tokens_ticket).  With them the
+   * worker lets dsm_worker_step_encode run up to three frames ahead of dsm_worker_step_model; without them one. */
+  int (*encode_async)(void* self, const float* pcm, const uint8_t* mask, int* ticket);
+  int (*step_ticket)(void* self, int ticket, const uint8_t* mask, uint32_t* text_tokens_out, float* prs_out);
 } dsm_worker_backend;
 int dsm_worker_create_with_backend(const dsm_worker_backend*, dsm_worker** out);
 void dsm_worker_destroy(dsm_worker*);
@@ -391,8 +415,15 @@ int dsm_worker_close(dsm_worker*, int slot);           /* the socket went away: 
  * larger than 64 MiB, or nested deeper than rmp_serde's limit of 1024: the reference logs and carries on),
  * DSM_ERR_STATE closed channel / OggOpus (no Opus decoder in this build). */
 int dsm_worker_send(dsm_worker*, int slot, const uint8_t* msgpack, size_t len);
-/* One pass of encoder_loop -> model_loop -> post_process (:314-522): 1 a step ran, 0 idle, <0 engine error. */
+/* One pass of encoder_loop -> model_loop -> post_process (:314-522) on the calling thread: 1 a step ran, 0 idle, <0 engine error. */
 int dsm_worker_step(dsm_worker*);
+/* The same work as the reference's threads split it (:314 encoder_loop, :432 model_loop + :414 post_process), for a host
+ * that runs them on two threads: dsm_worker_step_encode cuts the next frame from the sockets' queues, starts its Mimi encode and
+ * queues a PipelineMsg (1 produced, 0 idle or queue full); dsm_worker_step_model takes the oldest one through slot resets,
+ * step_tokens and the message fan-out (1 ran, 0 nothing queued).  With the engine as backend the encode of frame n+1 overlaps
+ * the LM step of frame n on the GPU; every client receives the same messages in the same order as with dsm_worker_step. */
+int dsm_worker_step_encode(dsm_worker*);
+int dsm_worker_step_model(dsm_worker*);
 /* Next serialised OutMsg for the slot's socket (send_loop, :960-985): 1 written, 0 none; *len = its size. */
 int dsm_worker_recv(dsm_worker*, int slot, uint8_t* buf, size_t cap, size_t* len);
 int dsm_worker_buffered(dsm_worker*, int slot);        /* samples waiting in the channel's queue (Step.buffered_pcm) */

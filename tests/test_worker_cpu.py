@@ -99,3 +99,34 @@ def test_idle_step_and_marker_without_audio(dsm, lib, orc, tiny_weights):
     # step 2, audio pass k is model step 3 + k
     assert [k for ks in got for k in ks].count("Marker") == 1 and "Marker" in got[max(0, cfg.asr_delay_in_tokens - 2)]
     w.close()
+
+
+def test_staged_calls_equal_the_single_call(dsm, lib, orc, tiny_weights):
+    """dsm_worker_step_encode + dsm_worker_step_model (the reference's encoder_loop / model_loop split, srv/batched_asr.rs:314,432)
+    against dsm_worker_step on a second worker: same messages per channel.  The oracle backend is synchronous (no tickets), so
+    the encode stage refuses to run ahead of an unconsumed frame."""
+    cfg = dsm.config_tiny()
+    B = 3
+    oa, ob = orc.OracleAsr(cfg, B, *tiny_weights), orc.OracleAsr(cfg, B, *tiny_weights)
+    (bea, keepa), (beb, keepb) = worker_ref.oracle_backend(dsm, oa, cfg, B), worker_ref.oracle_backend(dsm, ob, cfg, B)
+    wa, wb = dsm.Worker(backend=bea), dsm.Worker(backend=beb)
+    rng = np.random.default_rng(5)
+    slots = [wa.open() for _ in range(B)]
+    assert slots == [wb.open() for _ in range(B)]
+    for it in range(30):
+        for slot in slots:
+            if rng.random() < 0.8:
+                pcm = (0.1 * rng.standard_normal(int(rng.integers(500, 4000)))).astype(np.float32)
+                for w in (wa, wb):
+                    w.send(slot, dsm.encode_in_msg("Audio", pcm=pcm))
+            if rng.random() < 0.1:
+                for w in (wa, wb):
+                    w.send(slot, dsm.encode_in_msg("Marker", id=it))
+        ran_b = wb.step()
+        produced = wa.step_encode()
+        assert produced == ran_b
+        assert wa.step_encode() is False  # a synchronous backend holds one frame: no run-ahead
+        assert wa.step_model() == ran_b and wa.step_model() is False
+        for slot in slots:
+            assert wa.recv(slot) == wb.recv(slot)
+    wa.close(); wb.close()
