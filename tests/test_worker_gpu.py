@@ -25,27 +25,31 @@ def test_two_thread_run_ahead_pipeline_delivers_the_same_messages(gpu, dsm, lib,
     """The reference's thread pair (srv/batched_asr.rs:314 encoder_loop, :432 model_loop) on the engine: one thread keeps
     cutting and encoding frames (dsm_worker_step_encode, up to three ahead: dsm_mimi_encode_step_async), the other steps the
     LM and fans the messages out (dsm_worker_step_model: dsm_asr_step_tokens_ticket).  Every channel must receive what the
-    single-call worker delivers, in the same order (Step.buffered_pcm is the queue length when the frame was cut in both)."""
+    single-call worker delivers, in the same order (Step.buffered_pcm is the queue length when the frame was cut in both).
+    Frames arrive one per pass, as from real-time clients: like the reference, a pass that finds several queued Audio messages
+    for one channel keeps only the last complete frame (pre_process_pipelined drains the channel, :570-606)."""
     import threading
+    import time
     import numpy as np
     cfg = dsm.config_tiny()
     B, frames = 4, 40
     rng = np.random.default_rng(9)
-    audio = [[(0.1 * rng.standard_normal(1920)).astype(np.float32) for _ in range(frames)] for _ in range(B)]
+    audio = [[(0.1 * rng.standard_normal(1920 + int(rng.integers(0, 3)) * 64)).astype(np.float32) for _ in range(frames)] for _ in range(B)]
 
-    def feed(w, slots):
+    def feed(w, slots, f):
         for slot in slots:
-            for f in range(frames):
-                w.send(slot, dsm.encode_in_msg("Audio", pcm=audio[slot][f]))
-                if f % 9 == 4:
-                    w.send(slot, dsm.encode_in_msg("Marker", id=100 * slot + f))
+            w.send(slot, dsm.encode_in_msg("Audio", pcm=audio[slot][f]))
+            if f % 9 == 4:
+                w.send(slot, dsm.encode_in_msg("Marker", id=100 * slot + f))
 
     ea = dsm.AsrEngine(cfg, B, *tiny_weights)
     wa = dsm.Worker(ea)
     sa = [wa.open() for _ in range(B)]
-    feed(wa, sa)
-    while wa.step():
-        pass
+    for f in range(frames):
+        feed(wa, sa, f)
+        assert wa.step()
+    for _ in range(cfg.asr_delay_in_tokens + 8):  # let queued remainders and markers drain
+        wa.step()
     want = {s: wa.recv(s) for s in sa}
     wa.close(); ea.close()
 
@@ -53,28 +57,34 @@ def test_two_thread_run_ahead_pipeline_delivers_the_same_messages(gpu, dsm, lib,
     wb = dsm.Worker(eb)
     sb = [wb.open() for _ in range(B)]
     assert sb == sa
-    feed(wb, sb)
     done = threading.Event()
-    stats = {"ahead": 0, "errors": []}
+    stats = {"max_ahead": 0, "errors": [], "encoded": 0, "stepped": 0}
 
     def encoder_loop():
         try:
-            idle = 0
-            while idle < 200:
-                if wb.step_encode():
-                    idle = 0
-                else:
-                    idle += 1
-                    done.wait(0.0005)
+            for f in range(frames):
+                feed(wb, sb, f)
+                while not wb.step_encode():  # queue full: the model side is three frames behind
+                    time.sleep(0.0002)
+                stats["encoded"] += 1
+                stats["max_ahead"] = max(stats["max_ahead"], stats["encoded"] - stats["stepped"])
+            for _ in range(cfg.asr_delay_in_tokens + 8):
+                t0 = time.time()
+                while not wb.step_encode() and time.time() - t0 < 0.05:
+                    time.sleep(0.0002)
         except Exception as ex:  # pragma: no cover
             stats["errors"].append(ex)
         done.set()
 
     def model_loop():
         try:
-            while not done.is_set() or wb.step_model():
-                if not wb.step_model():
-                    done.wait(0.0002)
+            while True:
+                if wb.step_model():
+                    stats["stepped"] += 1
+                elif done.is_set():
+                    break
+                else:
+                    time.sleep(0.0001)
         except Exception as ex:  # pragma: no cover
             stats["errors"].append(ex)
 
@@ -85,6 +95,7 @@ def test_two_thread_run_ahead_pipeline_delivers_the_same_messages(gpu, dsm, lib,
         pass
     got = {s: wb.recv(s) for s in sb}
     for s in sa:
+        assert sum(m["type"] == "Step" for m in want[s]) >= frames
         assert got[s] == want[s], f"slot {s}: pipelined worker delivered different messages"
-        assert sum(m["type"] == "Step" for m in got[s]) == frames
+    assert stats["max_ahead"] >= 1
     wb.close(); eb.close()
