@@ -962,7 +962,10 @@ int run_captured(dsm_engine* e, dsm_engine::GraphSlot& gs, hipStream_t st, uint6
     if (gs.ws_gen != e->ws_gen) { gs.ws_gen = e->ws_gen; gs.warm = 0; }  // a workspace moved during this run
     return rc;
   }
-  HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+  // Relaxed mode: the body only launches kernels and async copies on `st`, and the host's OTHER thread (encoder vs model
+  // side) keeps calling synchronising APIs on its own streams meanwhile — under the thread-local mode ROCm 7.2 invalidated
+  // this capture when that happened (tests/test_worker_gpu.py, two-thread pipeline).
+  HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
   e->capturing = true;
   e->capture_failed = false;
   const int rc = body();
