@@ -183,7 +183,8 @@ struct dsm_engine {
   hipStream_t s_enc = nullptr, s_model = nullptr;
   static constexpr int kMaxGroups = 4;
   hipStream_t s_grp[kMaxGroups] = {nullptr, nullptr, nullptr, nullptr};  // s_grp[0] is unused (group 0 runs on s_model)
-  hipEvent_t ev_fork = nullptr, ev_grp_in[kMaxGroups] = {}, ev_grp_done[kMaxGroups] = {};
+  hipEvent_t ev_fork = nullptr, ev_grp_in[kMaxGroups] = {}, ev_grp_done[kMaxGroups] = {}, ev_stagger[kMaxGroups] = {};
+  bool stagger = true;  // DSM_STAGGER=0: every group starts its step at once (r01)
   bool grp_busy = false;
   bool fuse_qkv = true;  // DSM_FUSE_QKV=0: keep the separate QKV reduce launch
   bool chunk_loop = true;  // DSM_CHUNK_LOOP=0: always split K across workgroups

@@ -15,18 +15,16 @@ Bs = [int(x) for x in sys.argv[1:]] or [512, 2048]
 KNOBS = [
     {},                                            # defaults: rolling window depth 4, 2 groups, graphs
     {"DSM_ROLL": "0"},                             # r01 chunk loop
-    {"DSM_LOOP_DEPTH": "2"},
     {"DSM_LM_GROUPS": "4"},
-    {"DSM_LM_GROUPS": "4", "DSM_LOOP_DEPTH": "2"},
     {"DSM_LM_GROUPS": "3"},
     {"DSM_GRAPHS": "0"},
     {"DSM_ATTN_LDS_PAD": "0"},
-    {"DSM_GATE_OCC3": "1"},
-    {"DSM_GATE_OCC3": "1", "DSM_LM_GROUPS": "4"},
+    {"DSM_STAGGER": "0"},
+    {"DSM_STAGGER": "0", "DSM_LM_GROUPS": "4"},
 ]
 for B in Bs:
     for kn in KNOBS:
-        for k in ("DSM_ROLL", "DSM_LOOP_DEPTH", "DSM_LM_GROUPS", "DSM_GRAPHS", "DSM_ATTN_LDS_PAD", "DSM_GATE_OCC3"):
+        for k in ("DSM_ROLL", "DSM_LOOP_DEPTH", "DSM_LM_GROUPS", "DSM_GRAPHS", "DSM_ATTN_LDS_PAD", "DSM_GATE_OCC3", "DSM_STAGGER"):
             os.environ.pop(k, None)
         os.environ.update(kn)
         try:
