@@ -119,7 +119,7 @@ ABI_SYMBOLS = [
     "dsm_get_metrics", "dsm_batch_size", "dsm_n_q", "dsm_mimi_encode_step_dev", "dsm_asr_step_tokens_dev",
     "dsm_streams_join", "dsm_debug_read", "dsm_asr_step_pcm_dev", "dsm_prof_enable", "dsm_prof_read",
     "dsm_debug_set_positions", "dsm_mimi_decode_step", "dsm_mimi_decode_step_dev",
-    "dsm_lm_stream_groups", "dsm_debug_serialize_groups", "dsm_prof_read_device",
+    "dsm_lm_stream_groups", "dsm_debug_serialize_groups", "dsm_prof_read_device", "dsm_prof_timeline", "dsm_prof_timeline_read",
     "dsm_wav_decode", "dsm_free", "dsm_linear_resampler_new", "dsm_linear_resampler_process",
     "dsm_linear_resampler_free", "dsm_ogg_demux_new", "dsm_ogg_demux_free", "dsm_ogg_demux_push", "dsm_ogg_demux_next",
     "dsm_ogg_demux_info", "dsm_worker_set_opus_decoder", "dsm_ogg_mux_new", "dsm_ogg_mux_free", "dsm_ogg_mux_header", "dsm_ogg_mux_page",
@@ -698,6 +698,16 @@ class AsrEngine:
         cnt = (C.c_uint64 * len(PROF_TAGS))()
         self._check(self.lib.dsm_prof_read_device(self.h, tot, cnt))
         return {t: (tot[i], cnt[i]) for i, t in enumerate(PROF_TAGS)}
+
+    def prof_timeline(self, on):
+        self._check(self.lib.dsm_prof_timeline(self.h, 1 if on else 0))
+
+    def prof_timeline_read(self, cap=1 << 16):
+        """[(stream id, kind, tag name, start_us, end_us), ...] of every bracketed launch since the last read."""
+        sid, kind, tag = (C.c_int * cap)(), (C.c_int * cap)(), (C.c_int * cap)()
+        t0, t1 = (C.c_double * cap)(), (C.c_double * cap)()
+        n = self._check(self.lib.dsm_prof_timeline_read(self.h, sid, kind, tag, t0, t1, cap))
+        return [(sid[i], kind[i], PROF_TAGS[tag[i]], t0[i], t1[i]) for i in range(n)]
 
     def stream_groups(self):
         """[(first_slot, n_slots), ...] of the LM stream groups."""

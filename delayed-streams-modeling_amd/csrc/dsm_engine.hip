@@ -281,12 +281,18 @@ struct dsm_engine {
   static constexpr size_t kDevTsCap = 1 << 16;
   unsigned long long* dev_ts = nullptr;
   std::vector<int> dev_ts_tags;  // tag of record i (records are handed out in launch order)
-  unsigned long long* dev_ts_slot(int tag) {
+  std::vector<int> dev_ts_info;  // (stream id << 8) | kind of record i: 0 attention, 1 GEMM, 2 its reduce launch
+  bool timeline = false;         // dsm_prof_timeline: GEMM launches take records too (two each: the GEMM and its reduce)
+  unsigned long long* dev_ts_slot(int tag, int sid_ = 0, int kind = 0, int n = 1) {
     if (!dev_ts || !(prof_mask & (1u << tag))) return nullptr;
     std::lock_guard<std::mutex> lk(prof_mu);
-    if (dev_ts_tags.size() >= kDevTsCap) return nullptr;
-    dev_ts_tags.push_back(tag);
-    return dev_ts + 2 * (dev_ts_tags.size() - 1);
+    if (dev_ts_tags.size() + n > kDevTsCap) return nullptr;
+    unsigned long long* p = dev_ts + 2 * dev_ts_tags.size();
+    for (int i = 0; i < n; ++i) {
+      dev_ts_tags.push_back(tag);
+      dev_ts_info.push_back((sid_ << 8) | (kind + i));
+    }
+    return p;
   }
 
   hipEvent_t prof_event() {
@@ -860,6 +866,7 @@ int launch_gemm_tiled(dsm_engine* e, hipStream_t st, GemmArgs& a) {
     a.ws = e->gemm_ws[wsid];
   }
   dim3 grid(gx, chunks, (a.M + 16 * MT - 1) / (16 * MT));
+  a.ts = e->timeline ? e->dev_ts_slot(e->tag_gemm[e->sid(st)], e->sid(st), 1, 2) : nullptr;
   const int ph = e->prof_begin(e->tag_gemm[e->sid(st)], st);
   const bool roll = a.chunk_loop > 1 && e->roll_prefetch;  // whole K in the workgroup with a rolling load window
   constexpr int DMAX = LoopDepth<WT, NT>::MAX;

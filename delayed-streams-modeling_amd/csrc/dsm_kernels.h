@@ -77,7 +77,22 @@ struct GemmArgs {
   float* norm_out;
   float norm_eps;
   int norm_rms;
+  // optional device-clock bracket of the launch (timeline diagnostics, dsm_prof_timeline): {first workgroup in, last out}
+  unsigned long long* ts;
 };
+
+// first / last workgroups of a launch stamp the wall clock (dispatch is in index order; a few hundred atomics at most)
+__device__ __forceinline__ void launch_stamp_begin(unsigned long long* ts) {
+  if (!ts || threadIdx.x != 0) return;
+  const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  if (lin < 128) atomicMin(&ts[0], wall_clock64());
+}
+__device__ __forceinline__ void launch_stamp_end(unsigned long long* ts) {
+  if (!ts || threadIdx.x != 0) return;
+  const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+  const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  if (lin + 512 >= total) atomicMax(&ts[1], wall_clock64());
+}
 
 template <typename WT>
 __device__ __forceinline__ void load_w8(const WT* p, float (&o)[8]);
@@ -359,6 +374,7 @@ __global__ void gemm_mfma_kernel(GemmArgs a) {
 template <typename WT, typename KVT, int MT, int NT, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs a) {
   __shared__ __attribute__((aligned(16))) float Xs[2][16 * MT][DSM_XS_LD];
+  launch_stamp_begin(a.ts);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int chunks = gridDim.y;  // split-K across workgroups; 1 when a.chunk_loop walks the chunks below
@@ -500,6 +516,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs a) {
         *reinterpret_cast<f32x4*>(a.ws + ((long)blockIdx.y * mpad + m) * ld + n) = acc[nt][mt];
       }
     }
+    launch_stamp_end(a.ts);
     return;
   }
 #pragma unroll
@@ -518,6 +535,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs a) {
       }
     }
   }
+  launch_stamp_end(a.ts);
 }
 
 // ---- tiled GEMM, whole K inside the workgroup (large batches: the (n, m) tiles alone fill the chip, so there is no
@@ -537,6 +555,7 @@ struct LoopDepth {
 template <typename WT, typename KVT, int MT, int NT, int EPI, int D, int OCC = 2>
 __global__ __launch_bounds__(256, OCC) void gemm_loop_kernel(GemmArgs a) {
   static_assert(D == 2 || D == 4, "window depth");
+  launch_stamp_begin(a.ts);
   __shared__ __attribute__((aligned(16))) float Xs[2][16 * MT][DSM_XS_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
@@ -668,6 +687,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_loop_kernel(GemmArgs a) {
       }
     }
   }
+  launch_stamp_end(a.ts);
 }
 
 // Ordered sum of `chunks` slab values at p, p + cstride, ...: loads are issued eight at a time, the adds stay
@@ -691,6 +711,7 @@ __device__ __forceinline__ f32x4 slab_sum(const float* p, long cstride, int chun
 // Ordered split-K reduce + epilogue: one wave per 16x16 output tile (a gate/up tile pair for EPI_GATE).
 template <typename KVT, int EPI>
 __global__ __launch_bounds__(256) void gemm_reduce_kernel(GemmArgs a, int chunks) {
+  launch_stamp_begin(a.ts ? a.ts + 2 : nullptr);  // the reduce launch owns the record after its GEMM's
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int mtiles = (a.M + 15) >> 4;
@@ -712,6 +733,7 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(GemmArgs a, int chunks
     epi_rvq(a, tot[0], m, n, ntile, q);
   else
     epi_store_qkv<KVT, EPI>(a, tot[0], m, n);
+  launch_stamp_end(a.ts ? a.ts + 2 : nullptr);
 }
 
 // Canonical row reduction (dsm_numerics.h): 256 threads per row, thread t owns elements 1024*it + 4*t + j;
@@ -763,6 +785,7 @@ __device__ __forceinline__ void row_norm_apply(const float4 (&v)[DSM_ROW_ITS], f
 template <int ITS>  // 1024-element groups per row: ceil(d / 1024) rounded up to 1, 2 or 4
 __global__ __launch_bounds__(256) void gemm_reduce_rows_kernel(GemmArgs a, int chunks) {
   __shared__ float red[8];
+  launch_stamp_begin(a.ts ? a.ts + 2 : nullptr);
   const int m = blockIdx.x;
   const int d = a.N;
   const long ld = (long)a.ws_ntiles * 16, cstride = (long)((a.M + 15) >> 4) * 16 * ld;
@@ -823,6 +846,7 @@ __global__ __launch_bounds__(256) void gemm_reduce_rows_kernel(GemmArgs a, int c
   }
   block_row_sums(s, s2, red);
   row_norm_apply(v, s, s2, d, a.norm_eps, a.norm_rms, a.norm_w, a.norm_b, a.norm_out + (long)m * d);
+  launch_stamp_end(a.ts ? a.ts + 2 : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -247,6 +247,11 @@ int dsm_prof_read(dsm_engine*, double* total_us /*[DSM_PROF_NTAGS]*/, uint64_t* 
  * the duration rocprofv3's kernel trace reports.  With several streams in flight a HIP-event bracket also counts the
  * time a launch queues behind other streams' kernels.  Instrumented classes: ATTN_LM, ATTN_MIMI (others read 0). */
 int dsm_prof_read_device(dsm_engine*, double* total_us /*[DSM_PROF_NTAGS]*/, uint64_t* launches /*[DSM_PROF_NTAGS]*/);
+/* Timeline diagnostics (tools/timeline.py): with `on`, the tiled GEMM launches and their reduce launches are bracketed in the
+ * kernel like the attention launches; dsm_prof_timeline_read returns every bracketed launch since the last read as (stream id:
+ * 0 encoder, 1 + g LM group g; kind: 0 attention, 1 GEMM, 2 reduce; class tag; start / end in us from the earliest start). */
+int dsm_prof_timeline(dsm_engine*, int on);
+int dsm_prof_timeline_read(dsm_engine*, int* sid, int* kind, int* tag, double* start_us, double* end_us, int cap);
 
 /* ------------------------------------------------------------------------------------------------
  * TTS (BASELINE.json configs[4]): tts_streaming::State::step + LmModel::forward_cond + DepFormer::sample
