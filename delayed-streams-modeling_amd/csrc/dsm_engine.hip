@@ -189,6 +189,7 @@ struct dsm_engine {
   bool fuse_qkv = true;  // DSM_FUSE_QKV=0: keep the separate QKV reduce launch
   bool chunk_loop = true;  // DSM_CHUNK_LOOP=0: always split K across workgroups
   bool roll_prefetch = true;  // DSM_ROLL=0: the chunk loop requests a chunk only after finishing the previous one (r01 behaviour)
+  size_t gemm_lds_pad = 0;    // DSM_GEMM_LDS_PAD (bytes)
   bool gate_occ3 = false;     // DSM_GATE_OCC3=1: the gate's whole-K kernel squeezed to 168 VGPRs (three waves per SIMD, 80 B of spills)
   int loop_depth = 4;         // DSM_LOOP_DEPTH=2: two-block rolling window (fewer registers, three waves per SIMD) where four is the default
   size_t attn_lds_pad = 60000;  // DSM_ATTN_LDS_PAD: extra dynamic LDS per attention workgroup of a large launch (2 per CU)
@@ -871,12 +872,15 @@ int launch_gemm_tiled(dsm_engine* e, hipStream_t st, GemmArgs& a) {
   const bool roll = a.chunk_loop > 1 && e->roll_prefetch;  // whole K in the workgroup with a rolling load window
   constexpr int DMAX = LoopDepth<WT, NT>::MAX;
   const bool deep = DMAX == 4 && e->loop_depth == 4;
+  // extra dynamic LDS per GEMM workgroup (never touched): caps how many of them a CU takes, so that another stream's
+  // attention workgroups keep register file and wave slots beside them (DSM_GEMM_LDS_PAD, large launches only)
+  const size_t pad = ((long)grid.x * grid.y * grid.z >= 1024) ? e->gemm_lds_pad : 0;
 #define DSM_LAUNCH_TILED(MTv)                                                                                   \
   if (roll && NT == 2 && MTv == 4 && e->gate_occ3)                                                              \
-    hipLaunchKernelGGL((gemm_loop_kernel<WT, KVT, MTv, NT, EPI, 2, 3>), grid, dim3(256), 0, st, a);            \
-  else if (roll && deep) hipLaunchKernelGGL((gemm_loop_kernel<WT, KVT, MTv, NT, EPI, DMAX>), grid, dim3(256), 0, st, a); \
-  else if (roll) hipLaunchKernelGGL((gemm_loop_kernel<WT, KVT, MTv, NT, EPI, 2>), grid, dim3(256), 0, st, a);       \
-  else hipLaunchKernelGGL((gemm_tile_kernel<WT, KVT, MTv, NT, EPI>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((gemm_loop_kernel<WT, KVT, MTv, NT, EPI, 2, 3>), grid, dim3(256), pad, st, a);          \
+  else if (roll && deep) hipLaunchKernelGGL((gemm_loop_kernel<WT, KVT, MTv, NT, EPI, DMAX>), grid, dim3(256), pad, st, a); \
+  else if (roll) hipLaunchKernelGGL((gemm_loop_kernel<WT, KVT, MTv, NT, EPI, 2>), grid, dim3(256), pad, st, a);     \
+  else hipLaunchKernelGGL((gemm_tile_kernel<WT, KVT, MTv, NT, EPI>), grid, dim3(256), pad, st, a);
   if (MT == 4) { DSM_LAUNCH_TILED(4) } else if (MT == 2) { DSM_LAUNCH_TILED(2) } else { DSM_LAUNCH_TILED(1) }
 #undef DSM_LAUNCH_TILED
   const bool rows_ok = (EPI == EPI_STORE) && a.norm_out && a.vec && !a.Y2 && a.Y && a.N <= 4096 && a.ymap.bstride == 0;

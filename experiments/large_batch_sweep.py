@@ -13,18 +13,20 @@ arena = base.weight_arena()
 dev = torch.device("cuda", 0)
 Bs = [int(x) for x in sys.argv[1:]] or [512, 2048]
 KNOBS = [
-    {},                                            # defaults: rolling window depth 4, 2 groups, graphs
-    {"DSM_ROLL": "0"},                             # r01 chunk loop
-    {"DSM_LM_GROUPS": "4"},
-    {"DSM_LM_GROUPS": "3"},
-    {"DSM_GRAPHS": "0"},
-    {"DSM_ATTN_LDS_PAD": "0"},
+    {},                                            # defaults: rolling window depth 4, 2 groups, graphs, staggered start
     {"DSM_STAGGER": "0"},
-    {"DSM_STAGGER": "0", "DSM_LM_GROUPS": "4"},
+    {"DSM_GEMM_LDS_PAD": "24000"},                 # 3 GEMM workgroups per CU
+    {"DSM_GEMM_LDS_PAD": "40000"},                 # 2
+    {"DSM_GEMM_LDS_PAD": "40000", "DSM_ATTN_LDS_PAD": "0"},
+    {"DSM_GEMM_LDS_PAD": "70000"},                 # 1
+    {"DSM_GEMM_LDS_PAD": "70000", "DSM_ATTN_LDS_PAD": "0"},
+    {"DSM_GEMM_LDS_PAD": "40000", "DSM_ATTN_LDS_PAD": "30000"},
+    {"DSM_ATTN_LDS_PAD": "0"},
+    {"DSM_ATTN_LDS_PAD": "30000"},
 ]
 for B in Bs:
     for kn in KNOBS:
-        for k in ("DSM_ROLL", "DSM_LOOP_DEPTH", "DSM_LM_GROUPS", "DSM_GRAPHS", "DSM_ATTN_LDS_PAD", "DSM_GATE_OCC3", "DSM_STAGGER"):
+        for k in ("DSM_ROLL", "DSM_LOOP_DEPTH", "DSM_LM_GROUPS", "DSM_GRAPHS", "DSM_ATTN_LDS_PAD", "DSM_GATE_OCC3", "DSM_STAGGER", "DSM_GEMM_LDS_PAD"):
             os.environ.pop(k, None)
         os.environ.update(kn)
         try:
