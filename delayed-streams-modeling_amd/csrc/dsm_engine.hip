@@ -16,6 +16,7 @@
 #include <cstring>
 #include <atomic>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <vector>
 
@@ -184,7 +185,8 @@ struct dsm_engine {
   static constexpr int kMaxGroups = 4;
   hipStream_t s_grp[kMaxGroups] = {nullptr, nullptr, nullptr, nullptr};  // s_grp[0] is unused (group 0 runs on s_model)
   hipEvent_t ev_fork = nullptr, ev_grp_in[kMaxGroups] = {}, ev_grp_done[kMaxGroups] = {}, ev_stagger[kMaxGroups] = {};
-  bool stagger = true;  // DSM_STAGGER=0: every group starts its step at once (r01)
+  bool stagger = true;  // DSM_STAGGER=0: every group starts its step at once (r01); 2: staggered at every batch size
+  bool stagger_force = false;
   bool grp_busy = false;
   bool fuse_qkv = true;  // DSM_FUSE_QKV=0: keep the separate QKV reduce launch
   bool chunk_loop = true;  // DSM_CHUNK_LOOP=0: always split K across workgroups
@@ -257,6 +259,14 @@ struct dsm_engine {
   int pipe_next = 0;
   bool pipe_ready = false;
   std::mutex pipe_mu;
+  // Two host threads may drive one engine (dsm_mimi_encode_step_async / dsm_asr_step_tokens_ticket).  ROCm 7.2 now and then
+  // invalidates a stream capture ("operation failed due to a previous error during capture") while the process's OTHER
+  // thread is inside HIP calls of its own, in every capture mode — most likely its waits on events whose last record was
+  // on the stream that is capturing now (ev_consumed / ev_done), which the runtime then takes for captured events.  A
+  // capture therefore runs alone: the two entry points hold api_mu shared for the whole call, run_captured trades that
+  // for the exclusive side around Begin..Instantiate.
+  std::shared_mutex api_mu;
+  static thread_local std::shared_lock<std::shared_mutex>* api_held;
   // per-kernel-class event timing (dsm_prof_*)
   unsigned prof_mask = 0;
   // one slot per stream (0 = encoder, 1 = model): the two host threads of the worker never share a slot
@@ -391,6 +401,27 @@ struct dsm_engine {
 };
 
 thread_local bool dsm_engine::capturing = false;
+thread_local std::shared_lock<std::shared_mutex>* dsm_engine::api_held = nullptr;
+
+// shared side of dsm_engine::api_mu for the length of one API call on a two-thread entry point
+struct ApiShared {
+  std::shared_lock<std::shared_mutex> lk;
+  explicit ApiShared(dsm_engine* e) : lk(e->api_mu) { dsm_engine::api_held = &lk; }
+  ~ApiShared() { dsm_engine::api_held = nullptr; }
+};
+// exclusive side, for a capture: gives up this thread's shared hold first (two threads upgrading at once would deadlock)
+struct ApiExclusive {
+  std::shared_lock<std::shared_mutex>* held;
+  std::unique_lock<std::shared_mutex> lk;
+  explicit ApiExclusive(dsm_engine* e) : held(dsm_engine::api_held) {
+    if (held) held->unlock();
+    lk = std::unique_lock<std::shared_mutex>(e->api_mu);
+  }
+  ~ApiExclusive() {
+    lk.unlock();
+    if (held) held->lock();
+  }
+};
 
 // ----------------------------------------------------------------------------------------------
 // weight loading
@@ -977,6 +1008,7 @@ int run_captured(dsm_engine* e, dsm_engine::GraphSlot& gs, hipStream_t st, uint6
   // Relaxed mode: the body only launches kernels and async copies on `st`, and the host's OTHER thread (encoder vs model
   // side) keeps calling synchronising APIs on its own streams meanwhile — under the thread-local mode ROCm 7.2 invalidated
   // this capture when that happened (tests/test_worker_gpu.py, two-thread pipeline).
+  ApiExclusive alone(e);
   HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
   e->capturing = true;
   e->capture_failed = false;
