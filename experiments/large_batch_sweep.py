@@ -14,15 +14,11 @@ dev = torch.device("cuda", 0)
 Bs = [int(x) for x in sys.argv[1:]] or [512, 2048]
 KNOBS = [
     {},                                            # defaults: rolling window depth 4, 2 groups, graphs, staggered start
-    {"DSM_STAGGER": "0"},
-    {"DSM_GEMM_LDS_PAD": "24000"},                 # 3 GEMM workgroups per CU
-    {"DSM_GEMM_LDS_PAD": "40000"},                 # 2
-    {"DSM_GEMM_LDS_PAD": "40000", "DSM_ATTN_LDS_PAD": "0"},
-    {"DSM_GEMM_LDS_PAD": "70000"},                 # 1
-    {"DSM_GEMM_LDS_PAD": "70000", "DSM_ATTN_LDS_PAD": "0"},
-    {"DSM_GEMM_LDS_PAD": "40000", "DSM_ATTN_LDS_PAD": "30000"},
-    {"DSM_ATTN_LDS_PAD": "0"},
-    {"DSM_ATTN_LDS_PAD": "30000"},
+    {"DSM_ATTN_LDS_PAD": "100000"},                # ONE attention workgroup per CU
+    {"DSM_ATTN_LDS_PAD": "100000", "DSM_STAGGER": "0"},
+    {"DSM_ATTN_LDS_PAD": "100000", "DSM_LM_GROUPS": "4"},
+    {"DSM_ATTN_LDS_PAD": "80000"},
+    {"DSM_ATTN_LDS_PAD": "45000"},                 # 3
 ]
 for B in Bs:
     for kn in KNOBS:

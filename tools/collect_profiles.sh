@@ -1,0 +1,21 @@
+#!/bin/bash
+# Copies what tools/gpu_round.sh left under gpurun_out/prof/ (scratch) into profiles/<round>/ (tracked), under stable names.
+# usage: tools/collect_profiles.sh r02
+set -e
+R=${1:?round name}
+P=gpurun_out/prof
+D=profiles/$R
+mkdir -p $D
+cp $P/bench_default_run.json $D/bench_default_run.json
+cp $P/host_enqueue_eager.txt $P/host_enqueue_graphs.txt $D/
+cp $P/pmc_hbm_traffic.json $P/pmc_mfma_b64.json $P/pmc_mfma_b1024.json $D/
+# rocprofv3 writes one directory per traced process: keep the kernel-stats table of the one that ran the bench (the largest)
+for t in trace_1stream:kernel_stats_single_stream trace:kernel_stats_overlapped; do
+  src=${t%%:*}; dst=${t##*:}
+  f=$(ls -S $P/$src/*/*_kernel_stats.csv | head -1)
+  cp "$f" $D/$dst.csv
+  grep '^{' $P/${src}_bench.json > $D/$dst.bench.json || true
+done
+python3 tools/trace_summary.py $P/trace_1stream 14 > $D/kernel_trace_single_stream_summary.txt
+python3 tools/trace_summary.py $P/trace 14 > $D/kernel_trace_overlapped_summary.txt
+ls -la $D
