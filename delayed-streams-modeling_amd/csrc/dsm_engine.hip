@@ -918,8 +918,8 @@ int launch_gemm_tiled(dsm_engine* e, hipStream_t st, GemmArgs& a) {
   if (chunks > 1 && !(EPI == EPI_QKV && a.defer_reduce)) {
     if (rows_ok) {
       if (a.N <= 1024) hipLaunchKernelGGL(gemm_reduce_rows_kernel<1>, dim3(a.M), dim3(256), 0, st, a, chunks);
-      else if (a.N <= 2048) hipLaunchKernelGGL(gemm_reduce_rows_kernel<2>, dim3(a.M), dim3(256), 0, st, a, chunks);
-      else hipLaunchKernelGGL(gemm_reduce_rows_kernel<4>, dim3(a.M), dim3(256), 0, st, a, chunks);
+      else if (a.N <= 2048) hipLaunchKernelGGL(gemm_reduce_rows_kernel<2>, dim3(a.M), dim3(512), 0, st, a, chunks);
+      else hipLaunchKernelGGL(gemm_reduce_rows_kernel<4>, dim3(a.M), dim3(1024), 0, st, a, chunks);
     } else {
       const int out_tiles = mtiles * ((a.N + 15) / 16);
       hipLaunchKernelGGL((gemm_reduce_kernel<KVT, EPI>), dim3((out_tiles + 3) / 4), dim3(256), 0, st, a, chunks);

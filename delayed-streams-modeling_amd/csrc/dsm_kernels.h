@@ -781,71 +781,97 @@ __device__ __forceinline__ void row_norm_apply(const float4 (&v)[DSM_ROW_ITS], f
 
 // Ordered split-K reduce + STORE epilogue (bias / act / scale / residual) + the row norm that follows it, one
 // workgroup per output row (N = d_model).  Same per-element arithmetic as epi_store_qkv<EPI_STORE> followed by
-// row_norm_kernel.
+// row_norm_kernel, and the same canonical row reduction (dsm_numerics.h: thread t of 256 chains its elements
+// 1024*it + 4*t + j over it = 0, 1, ...) — but the work of "thread t" is spread over ITS threads, one per 1024-element group
+// (workgroup of 256 * ITS threads), so that every slab load of the row is in flight at once: a launch has only M
+// workgroups (32 per stream group at B = 64) and its time is the number of dependent load rounds.  The chain over `it`
+// is handed from group to group through LDS (ITS - 1 barriers of ALU work).  r01 form: 256 threads, eight chunks of every
+// group per round = three rounds for the 22-chunk ff_out reduce, 6.8 us per launch.
 template <int ITS>  // 1024-element groups per row: ceil(d / 1024) rounded up to 1, 2 or 4
-__global__ __launch_bounds__(256) void gemm_reduce_rows_kernel(GemmArgs a, int chunks) {
+__global__ __launch_bounds__(256 * ITS) void gemm_reduce_rows_kernel(GemmArgs a, int chunks) {
+  constexpr int RS = ITS == 4 ? 16 : 24;  // chunk loads per round (VGPR budget: 1024 threads leave 128 each)
   __shared__ float red[8];
+  __shared__ float carry[2][256];
   launch_stamp_begin(a.ts ? a.ts + 2 : nullptr);
   const int m = blockIdx.x;
   const int d = a.N;
+  const int it = threadIdx.x >> 8, t = threadIdx.x & 255;
   const long ld = (long)a.ws_ntiles * 16, cstride = (long)((a.M + 15) >> 4) * 16 * ld;
-  const float* p = a.ws + (long)m * ld;
-  const float* rp = a.res ? a.res + a.rmap.off(m) : nullptr;
-  float* yp = a.Y + a.ymap.off(m);
-  float4 v[DSM_ROW_ITS];
-  float s = 0.0f, s2 = 0.0f;
-  // ordered slab sums of the thread's (up to) four 4-element groups, the loads of all groups and of eight chunks in
-  // flight together: with one group at a time the 22-chunk ff_out reduce was six dependent load rounds
-  f32x4 t[ITS];
-  int off[ITS];  // clamped element offset: a group beyond d re-reads the thread's first group and is dropped
+  const int i = it * 1024 + 4 * t;
+  const bool live = i < d;
+  const float* p = a.ws + (long)m * ld + (live ? i : 4 * t);  // a group beyond d re-reads the row's first group and is dropped
+  f32x4 tot = *reinterpret_cast<const f32x4*>(p);
+  for (int c0 = 1; c0 < chunks; c0 += RS) {
+    f32x4 w[RS];
 #pragma unroll
-  for (int it = 0; it < ITS; ++it) {
-    const int i = it * 1024 + 4 * (int)threadIdx.x;
-    off[it] = i < d ? i : 4 * (int)threadIdx.x;
-    t[it] = *reinterpret_cast<const f32x4*>(p + off[it]);
-  }
-  for (int c0 = 1; c0 < chunks; c0 += 8) {
-    f32x4 w[ITS][8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < RS; ++u) {
       const int c = c0 + u < chunks ? c0 + u : chunks - 1;  // clamped duplicate load, discarded below
-#pragma unroll
-      for (int it = 0; it < ITS; ++it) w[it][u] = *reinterpret_cast<const f32x4*>(p + off[it] + c * cstride);
+      w[u] = *reinterpret_cast<const f32x4*>(p + c * cstride);
     }
+    __builtin_amdgcn_sched_barrier(0);  // every load of the round is issued before the first add waits
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (c0 + u < chunks) {
-#pragma unroll
-        for (int it = 0; it < ITS; ++it) t[it] = t[it] + w[it][u];
-      }
+    for (int u = 0; u < RS; ++u)
+      if (c0 + u < chunks) tot = tot + w[u];
   }
+  float o[4] = {tot[0], tot[1], tot[2], tot[3]};
+  if (live) {
 #pragma unroll
-  for (int it = 0; it < DSM_ROW_ITS; ++it) v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-  for (int it = 0; it < ITS; ++it) {
-    const int i = it * 1024 + 4 * (int)threadIdx.x;
-    if (i < d) {
-      float o[4] = {t[it][0], t[it][1], t[it][2], t[it][3]};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (a.bias) o[j] = o[j] + a.bias[i + j];
-        if (a.act == 1) o[j] = dsm_gelu_erf(o[j]);
-        if (a.scale) o[j] = o[j] * a.scale[i + j];
-      }
-      if (rp) {
-        const float4 rv = *reinterpret_cast<const float4*>(rp + i);
-        o[0] = rv.x + o[0]; o[1] = rv.y + o[1]; o[2] = rv.z + o[2]; o[3] = rv.w + o[3];
-      }
-      v[it] = make_float4(o[0], o[1], o[2], o[3]);
-      *reinterpret_cast<float4*>(yp + i) = v[it];
-      s = s + o[0]; s2 = DSM_FMAF(o[0], o[0], s2);
-      s = s + o[1]; s2 = DSM_FMAF(o[1], o[1], s2);
-      s = s + o[2]; s2 = DSM_FMAF(o[2], o[2], s2);
-      s = s + o[3]; s2 = DSM_FMAF(o[3], o[3], s2);
+    for (int j = 0; j < 4; ++j) {
+      if (a.bias) o[j] = o[j] + a.bias[i + j];
+      if (a.act == 1) o[j] = dsm_gelu_erf(o[j]);
+      if (a.scale) o[j] = o[j] * a.scale[i + j];
     }
+    if (a.res) {
+      const float4 rv = *reinterpret_cast<const float4*>(a.res + a.rmap.off(m) + i);
+      o[0] = rv.x + o[0]; o[1] = rv.y + o[1]; o[2] = rv.z + o[2]; o[3] = rv.w + o[3];
+    }
+    *reinterpret_cast<float4*>(a.Y + a.ymap.off(m) + i) = make_float4(o[0], o[1], o[2], o[3]);
   }
-  block_row_sums(s, s2, red);
-  row_norm_apply(v, s, s2, d, a.norm_eps, a.norm_rms, a.norm_w, a.norm_b, a.norm_out + (long)m * d);
+  // thread t's chain, continued group by group
+  float s = 0.0f, s2 = 0.0f;
+#pragma unroll
+  for (int k = 0; k < ITS; ++k) {
+    if (it == k) {
+      if (k > 0) { s = carry[0][t]; s2 = carry[1][t]; }
+      if (live) {
+        s = s + o[0]; s2 = DSM_FMAF(o[0], o[0], s2);
+        s = s + o[1]; s2 = DSM_FMAF(o[1], o[1], s2);
+        s = s + o[2]; s2 = DSM_FMAF(o[2], o[2], s2);
+        s = s + o[3]; s2 = DSM_FMAF(o[3], o[3], s2);
+      }
+      if (k + 1 < ITS) { carry[0][t] = s; carry[1][t] = s2; }
+    }
+    if (k + 1 < ITS) __syncthreads();
+  }
+  if (it == ITS - 1) {  // these 4 waves hold the 256 thread totals: wave butterflies, then the wave totals left to right
+    const int lane = t & 63, wave = t >> 6;
+    s = wave_sum64(s);
+    s2 = wave_sum64(s2);
+    if (lane == 0) { red[wave] = s; red[4 + wave] = s2; }
+  }
+  __syncthreads();
+  s = ((red[0] + red[1]) + red[2]) + red[3];
+  s2 = ((red[4] + red[5]) + red[6]) + red[7];
+  if (live) {
+    float mm = 1.f, mean = 0.f, inv = 0.f;
+    if (a.norm_rms) {
+      mm = sqrtf(s2 / (float)d + a.norm_eps);
+    } else {
+      mean = s / (float)d;
+      float var = s2 / (float)d - mean * mean;
+      inv = 1.0f / sqrtf(var + a.norm_eps);
+    }
+    const float4 wv = *reinterpret_cast<const float4*>(a.norm_w + i);
+    float4 r;
+    if (a.norm_rms) {
+      r.x = (o[0] / mm) * wv.x; r.y = (o[1] / mm) * wv.y; r.z = (o[2] / mm) * wv.z; r.w = (o[3] / mm) * wv.w;
+    } else {
+      const float4 bv = *reinterpret_cast<const float4*>(a.norm_b + i);
+      r.x = ((o[0] - mean) * inv) * wv.x + bv.x; r.y = ((o[1] - mean) * inv) * wv.y + bv.y;
+      r.z = ((o[2] - mean) * inv) * wv.z + bv.z; r.w = ((o[3] - mean) * inv) * wv.w + bv.w;
+    }
+    *reinterpret_cast<float4*>(a.norm_out + (long)m * d + i) = r;
+  }
   launch_stamp_end(a.ts ? a.ts + 2 : nullptr);
 }
 

@@ -1,0 +1,80 @@
+"""Full-size property test (BASELINE.json configs[1] scaled to the capacity leg): at B = 1024 on real stt-1b-en_fr dimensions
+the step runs kernels no oracle-sized test reaches — `gemm_loop_kernel` with 64-row tiles over 8 m-tiles per stream
+group, the staggered group start (>= 256 slots per group), attention launches of 8192 workgroups with the LDS occupancy
+cap — and one oracle step at that size would take minutes.  The domain offers a size-independent property instead:
+streams never interact (core/asr.rs:147-252 steps every slot with its own state), so
+
+  * slots fed the same audio must produce the same codes, tokens, VAD and hidden states, bit for bit, wherever they sit
+    in the batch (first / second stream group, first / last m-tile, ragged positions), and
+  * they must equal a B = 4 engine stepping those four streams alone — whose kernels (16-row tiles, split-K slabs, fused
+    QKV prologue) ARE compared with the oracle at these dimensions (tests/test_parity_full_gpu.py, test_batch_shapes_gpu.py).
+
+Runs from reset with mixed masks and one mid-run slot reset; the ring is then jumped to a wrapped steady state
+(dsm_debug_set_positions) and the property is checked again on full-length attention."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+WEIGHTS_DIR = os.environ.get("DSM_WEIGHTS_DIR", "/tmp/dsm_weights")
+
+
+def _run(eng, cfg, B, pcm, masks, reset_at, reset_slots, taps):
+    out = []
+    for s in range(len(pcm)):
+        if s == reset_at:
+            for slot in reset_slots:
+                eng.reset_batch_idx(slot)
+        codes, toks, prs = eng.step_pcm(pcm[s], masks[s])
+        rec = {"codes": codes.copy(), "toks": toks.copy(), "prs": prs.copy()}
+        if taps:
+            rec["hid"] = eng.debug_read("lm.hidden", B * cfg.lm.d_model).reshape(B, -1).copy()
+        out.append(rec)
+    return out
+
+
+def test_b1024_slots_with_equal_audio_agree_and_match_b4(gpu, dsm, lib):
+    from dsm_amd import synth
+    cfg = dsm.config_stt_1b_en_fr()
+    lm, mimi = synth.make_synth_weights(cfg, WEIGHTS_DIR, tag="stt-1b-en_fr")
+    B, NS, steps = 1024, 4, 4
+    rng = np.random.default_rng(21)
+    src_pcm = synth.synth_pcm(NS, steps, seed=77)                  # [steps][NS][1920]
+    src_mask = (rng.random((steps, NS)) < 0.85).astype(np.uint8)
+    src_mask[0] = 1
+    owner = rng.integers(0, NS, B)                                  # which source stream a slot carries
+    owner[[0, 1, 2, 3, 511, 512, 513, 1020, 1021, 1022, 1023]] = [0, 1, 2, 3, 0, 1, 2, 3, 0, 1, 2]
+    pcm = [np.ascontiguousarray(src_pcm[s][owner]) for s in range(steps)]
+    masks = [np.ascontiguousarray(src_mask[s][owner]) for s in range(steps)]
+    reset_src = 2                                                   # every slot carrying stream 2 is reset before step 2
+    small = dsm.AsrEngine(cfg, NS, lm, mimi)
+    want = _run(small, cfg, NS, [src_pcm[s] for s in range(steps)], [src_mask[s] for s in range(steps)], 2, [reset_src], True)
+    big = dsm.AsrEngine(cfg, B, lm, mimi, arena=small.weight_arena())
+    assert len(big.stream_groups()) == 2 and big.stream_groups()[0][1] >= 256, "the staggered start must be active"
+    got = _run(big, cfg, B, pcm, masks, 2, [int(b) for b in np.nonzero(owner == reset_src)[0]], True)
+    for s in range(steps):
+        act = masks[s].astype(bool)
+        for key in ("codes", "toks", "hid"):
+            g, w = got[s][key], want[s][key][owner]
+            if g.dtype == np.float32:
+                g, w = g.view(np.uint32), w.view(np.uint32)
+            assert np.array_equal(g[act], w[act]), f"step {s}: {key} of a B=1024 slot differs from the same stream at B=4"
+        gp, wp = got[s]["prs"].view(np.uint32), want[s]["prs"][:, owner].view(np.uint32)
+        assert np.array_equal(gp[:, act], wp[:, act]), f"step {s}: VAD differs"
+    # steady state: wrapped ring (positions far past the 750-frame context), full-length attention in both engines
+    for eng in (small, big):
+        eng.debug_set_positions(3 * cfg.lm.context + 11, 3 * cfg.mimi.transformer.context + 5)
+    ones_s, ones_b = np.ones(NS, np.uint8), np.ones(B, np.uint8)
+    more = synth.synth_pcm(NS, 2, seed=78)
+    for s in range(2):
+        cs, ts, ps = small.step_pcm(more[s], ones_s)
+        hs = small.debug_read("lm.hidden", NS * cfg.lm.d_model).reshape(NS, -1).copy()
+        cb, tb, pb = big.step_pcm(np.ascontiguousarray(more[s][owner]), ones_b)
+        hb = big.debug_read("lm.hidden", B * cfg.lm.d_model).reshape(B, -1)
+        assert np.array_equal(cb, cs[owner]) and np.array_equal(tb, ts[owner]), f"steady step {s}: codes / tokens differ"
+        assert np.array_equal(hb.view(np.uint32), hs[owner].view(np.uint32)), f"steady step {s}: hidden state differs"
+        assert np.array_equal(pb.view(np.uint32), ps[:, owner].view(np.uint32)), f"steady step {s}: VAD differs"
+    big.close()
+    small.close()
