@@ -195,6 +195,9 @@ struct dsm_engine {
   bool gate_occ3 = false;     // DSM_GATE_OCC3=1: the gate's whole-K kernel squeezed to 168 VGPRs (three waves per SIMD, 80 B of spills)
   int loop_depth = 4;         // DSM_LOOP_DEPTH=2: two-block rolling window (fewer registers, three waves per SIMD) where four is the default
   size_t attn_lds_pad = 60000;  // DSM_ATTN_LDS_PAD: extra dynamic LDS per attention workgroup of a large launch (2 per CU)
+  int smallk_loop = 1;        // DSM_SMALLK_LOOP=0: one-chunk GEMMs (K <= 256) over many m-tiles stay on gemm_tile_kernel (r01)
+  int smallk_min_tiles = 1024;  // DSM_SMALLK_MIN: from how many 64-row tiles on
+  int smallk_mt = 4;          // DSM_SMALLK_MT: 16-row tiles per workgroup of those launches
   int chunk_loop_min_tiles = 384;  // DSM_CHUNK_LOOP_MIN (swept at B = 512 / 1024: 384 best)
   int prio_hi = 0;
   bool serialize_groups = false;  // dsm_debug_serialize_groups: every group on the model stream (profiling aid)
@@ -872,6 +875,12 @@ int launch_gemm_tiled(dsm_engine* e, hipStream_t st, GemmArgs& a) {
   }
   int MT = a.M > 32 ? 4 : (a.M > 16 ? 2 : 1);
   while (MT > 1 && (long)gx * chunks * ((a.M + 16 * MT - 1) / (16 * MT)) < 256) MT /= 2;  // cover the 256 CUs
+  // one K-chunk and thousands of m-tiles (the first SEANet layers at large batches: K = 32..192, M = B x 1920): a
+  // workgroup is one short dependent chain — loads, one to six MFMA blocks, residual load, store — so what counts is how
+  // many of them a CU holds; gemm_tile_kernel's up-front window of eight blocks costs 200-230 VGPRs (two workgroups per CU),
+  // gemm_loop_kernel's two-block window 150 (three).  Mimi encode alone at B = 2048: 17.7 -> 16.6 ms; 8-row tiles no better.
+  const bool smallk = e->smallk_loop && chunks == 1 && a.chunk_loop == 0 && (long)gx * ((a.M + 63) / 64) >= e->smallk_min_tiles;
+  if (smallk && e->smallk_mt < MT) MT = e->smallk_mt;
   auto ok4 = [](const RowMap& m) { return m.ld % 4 == 0 && m.bstride % 4 == 0; };
   a.vec = (a.N % 4 == 0) && (!a.Y || ok4(a.ymap)) && (!a.Y2 || ok4(a.y2map)) && (!a.res || ok4(a.rmap));
   a.ws_ntiles = (((NT - 1) * a.nt_stride) >> 4) + gx * 4;
@@ -900,9 +909,9 @@ int launch_gemm_tiled(dsm_engine* e, hipStream_t st, GemmArgs& a) {
   dim3 grid(gx, chunks, (a.M + 16 * MT - 1) / (16 * MT));
   a.ts = e->timeline ? e->dev_ts_slot(e->tag_gemm[e->sid(st)], e->sid(st), 1, 2) : nullptr;
   const int ph = e->prof_begin(e->tag_gemm[e->sid(st)], st);
-  const bool roll = a.chunk_loop > 1 && e->roll_prefetch;  // whole K in the workgroup with a rolling load window
+  const bool roll = (a.chunk_loop > 1 && e->roll_prefetch) || smallk;  // whole K in the workgroup with a rolling load window
   constexpr int DMAX = LoopDepth<WT, NT>::MAX;
-  const bool deep = DMAX == 4 && e->loop_depth == 4;
+  const bool deep = DMAX == 4 && e->loop_depth == 4 && !smallk;
   // extra dynamic LDS per GEMM workgroup (never touched): caps how many of them a CU takes, so that another stream's
   // attention workgroups keep register file and wave slots beside them (DSM_GEMM_LDS_PAD, large launches only)
   const size_t pad = ((long)grid.x * grid.y * grid.z >= 1024) ? e->gemm_lds_pad : 0;

@@ -13,12 +13,7 @@ arena = base.weight_arena()
 dev = torch.device("cuda", 0)
 Bs = [int(x) for x in sys.argv[1:]] or [512, 2048]
 KNOBS = [
-    {},                                            # defaults: rolling window depth 4, 2 groups, graphs, staggered start
-    {"DSM_ATTN_LDS_PAD": "100000"},                # ONE attention workgroup per CU
-    {"DSM_ATTN_LDS_PAD": "100000", "DSM_STAGGER": "0"},
-    {"DSM_ATTN_LDS_PAD": "100000", "DSM_LM_GROUPS": "4"},
-    {"DSM_ATTN_LDS_PAD": "80000"},
-    {"DSM_ATTN_LDS_PAD": "45000"},                 # 3
+    {},                                            # defaults: rolling window depth 4, 2 groups, graphs, staggered start from 256 slots per group
 ]
 for B in Bs:
     for kn in KNOBS:

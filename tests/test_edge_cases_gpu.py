@@ -175,6 +175,25 @@ def test_whole_k_loop_kernel_on_small_models(gpu, dsm, lib, orc, tiny_weights, m
     run_pair(dsm, orc, cfg, 4, lm, mimi, steps=10, mask_fn=lambda s: masks[s], resets={6: [2]})
 
 
+@pytest.mark.parametrize("mt", ["4", "2", "1"])
+def test_one_chunk_gemms_through_the_loop_kernel(gpu, dsm, lib, orc, tiny_weights, monkeypatch, mt):
+    """One-chunk GEMMs (K <= 256: the first SEANet layers, the RVQ projections) take gemm_loop_kernel instead of
+    gemm_tile_kernel once they span >= 1024 m-tiles (B >= 35 on real Mimi) — a size no oracle run reaches.  DSM_SMALLK_MIN=1
+    sends every such GEMM of the tiny and the medium model down that path, with each tile height: same bits as the oracle."""
+    import os
+    from dsm_amd import synth
+    from test_parity_gpu import run_pair
+    monkeypatch.setenv("DSM_SMALLK_MIN", "1")
+    monkeypatch.setenv("DSM_SMALLK_MT", mt)
+    rng = np.random.default_rng(4)
+    masks = (rng.random((10, 5)) < 0.8).astype(np.uint8)
+    masks[:, 0] = 1
+    run_pair(dsm, orc, dsm.config_tiny(), 5, *tiny_weights, steps=10, mask_fn=lambda s: masks[s], resets={4: [1]})
+    cfg = dsm.config_medium()
+    lm, mimi = synth.make_synth_weights(cfg, os.environ.get("DSM_WEIGHTS_DIR", "/tmp/dsm_weights"), tag="medium_bf16_hd128_ctx300")
+    run_pair(dsm, orc, cfg, 5, lm, mimi, steps=6, mask_fn=lambda s: masks[s], resets={4: [1]})
+
+
 def test_wide_model_d4096(gpu, dsm, lib, orc):
     """d_model = 4096 is the widest row the row kernels take (`DSM_ROW_ITS` = 4 float4 per thread) and the only width
     that reaches `gemm_reduce_rows_kernel<4>`; every shipped model stops at 2048, so this one-layer LM (32 heads of 128,
