@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true", help="single-stream step_pcm instead of the encoder/model stream pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
-    ap.add_argument("--capacity-legs", default="400,2048",
+    ap.add_argument("--capacity-legs", default="400,2048,2176",
                     help="comma-separated larger batches timed after the headline run (N = 1 only; '' to skip)")
     ap.add_argument("--part", default="all", choices=["all", "lm", "enc"],
                     help="experiment: time only the LM step (codes fed from a fixed device buffer) or only the Mimi encode")

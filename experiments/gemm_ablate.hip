@@ -6,12 +6,13 @@
 #include <cstdlib>
 #include <vector>
 #include "dsm_kernels.h"
+#define DSM_XS_LD_R01 36  // the padded LDS rows these ablations were measured with (the product kernels swizzle since r02)
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP %s @%d\n", hipGetErrorString(e_), __LINE__); exit(2);} } while (0)
 
 template <int MT, int ABL, int KCH>
 __global__ __launch_bounds__(256, 2) void abl_kernel(const float* __restrict__ X, const uint16_t* __restrict__ W, float* __restrict__ ws,
                                                      int M, int Kpad, int ldx) {
-  __shared__ __attribute__((aligned(16))) float Xs[2][16 * MT][DSM_XS_LD];
+  __shared__ __attribute__((aligned(16))) float Xs[2][16 * MT][DSM_XS_LD_R01];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int chunk = blockIdx.y;
@@ -21,7 +22,7 @@ __global__ __launch_bounds__(256, 2) void abl_kernel(const float* __restrict__ X
   const int row0 = tid >> 3, part = tid & 7;
   const float* xsrc0 = X + (long)row0 * ldx + 4 * part;
   const float* xsrc1 = X + (long)(row0 + 32) * ldx + 4 * part;
-  const int xdst0 = row0 * DSM_XS_LD + 4 * part, xdst1 = (row0 + 32) * DSM_XS_LD + 4 * part;
+  const int xdst0 = row0 * DSM_XS_LD_R01 + 4 * part, xdst1 = (row0 + 32) * DSM_XS_LD_R01 + 4 * part;
   f32x4 acc[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256, 2) void abl_kernel(const float* __restrict__ X
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       if (!(ABL & 4)) {
-        const float* fp = xs + (16 * mt + r) * DSM_XS_LD + 8 * q;
+        const float* fp = xs + (16 * mt + r) * DSM_XS_LD_R01 + 8 * q;
         float4 f0 = *reinterpret_cast<const float4*>(fp), f1 = *reinterpret_cast<const float4*>(fp + 4);
         xb[mt][0] = f0.x; xb[mt][1] = f0.y; xb[mt][2] = f0.z; xb[mt][3] = f0.w;
         xb[mt][4] = f1.x; xb[mt][5] = f1.y; xb[mt][6] = f1.z; xb[mt][7] = f1.w;

@@ -10,20 +10,21 @@
 #include <cstring>
 #include <vector>
 #include "dsm_kernels.h"
+#define DSM_XS_LD_R01 36  // the padded LDS rows these ablations were measured with (the product kernels swizzle since r02)
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP %s @%d\n", hipGetErrorString(e_), __LINE__); exit(2);} } while (0)
 
 template <int ABL, int OCC>
 __global__ __launch_bounds__(256, OCC) void loop_abl(const float* __restrict__ X, const uint16_t* __restrict__ W, float* __restrict__ Y,
                                                       int M, int N, int K) {
   constexpr int MT = 4, D = 4;
-  __shared__ __attribute__((aligned(16))) float Xs[2][16 * MT][DSM_XS_LD];
+  __shared__ __attribute__((aligned(16))) float Xs[2][16 * MT][DSM_XS_LD_R01];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
   const int m_base = blockIdx.z * 64, n_base = blockIdx.x * 64 + 16 * wave;
   const uint16_t* wrow = W + (long)(n_base + r) * K + 8 * q;
   const int row0 = tid >> 3, part = tid & 7;
   const float* xsrc0 = X + (long)(m_base + row0) * K + 4 * part;
   const float* xsrc1 = X + (long)(m_base + row0 + 32) * K + 4 * part;
-  const int xdst0 = row0 * DSM_XS_LD + 4 * part, xdst1 = (row0 + 32) * DSM_XS_LD + 4 * part;
+  const int xdst0 = row0 * DSM_XS_LD_R01 + 4 * part, xdst1 = (row0 + 32) * DSM_XS_LD_R01 + 4 * part;
   const int nb = K >> 5;
   f32x4 acc[MT], tot[MT];
   for (int mt = 0; mt < MT; ++mt) { acc[mt] = (f32x4){0, 0, 0, 0}; tot[mt] = (f32x4){0, 0, 0, 0}; }
@@ -36,7 +37,7 @@ __global__ __launch_bounds__(256, OCC) void loop_abl(const float* __restrict__ X
 #define LSTORE(S, BUF) if (!(ABL & 2)) { float* xs_ = &Xs[BUF][0][0]; *reinterpret_cast<float4*>(xs_ + xdst0) = xp##S; *reinterpret_cast<float4*>(xs_ + xdst1) = xq##S; }
 #define LFRAG(XB, BUF, S) for (int mt = 0; mt < MT; ++mt) { \
     if (ABL & 2) { for (int j = 0; j < 8; ++j) XB[mt][j] = xp##S.x + (float)(mt + j); } else { \
-    const float* fp = &Xs[BUF][0][0] + (16 * mt + r) * DSM_XS_LD + 8 * q; \
+    const float* fp = &Xs[BUF][0][0] + (16 * mt + r) * DSM_XS_LD_R01 + 8 * q; \
     const float4 f0 = *reinterpret_cast<const float4*>(fp), f1 = *reinterpret_cast<const float4*>(fp + 4); \
     XB[mt][0] = f0.x; XB[mt][1] = f0.y; XB[mt][2] = f0.z; XB[mt][3] = f0.w; XB[mt][4] = f1.x; XB[mt][5] = f1.y; XB[mt][6] = f1.z; XB[mt][7] = f1.w; } }
 #define LMFMA(CUR, S0, S1) for (int s = (S0); s < (S1); ++s) { \
