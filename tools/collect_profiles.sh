@@ -18,4 +18,9 @@ for t in trace_1stream:kernel_stats_single_stream trace:kernel_stats_overlapped;
 done
 python3 tools/trace_summary.py $P/trace_1stream 14 > $D/kernel_trace_single_stream_summary.txt
 python3 tools/trace_summary.py $P/trace 14 > $D/kernel_trace_overlapped_summary.txt
-ls -la $D
+if [ -d $P/extra ]; then
+  mkdir -p $D/extra
+  for f in $P/extra/*.json; do grep '^{' "$f" > $D/extra/$(basename "$f") || true; done
+  cp $P/extra/*.txt $D/extra/ 2>/dev/null || true
+fi
+ls -la $D $D/extra

@@ -24,5 +24,19 @@ step pmc_mfma64 300 rocprofv3 --pmc $MF --output-format csv -d $P/pmc_mfma_b64 -
 python3 tools/pmc_mfma_summary.py $P/pmc_mfma_b64 30 > $P/pmc_mfma_b64.json
 step pmc_mfma1024 300 rocprofv3 --pmc $MF --output-format csv -d $P/pmc_mfma_b1024 -- python3 bench.py --batch 1024 --fast-fill --no-overlap --steps 2 --warmup 1 --no-cpu-baseline --capacity-legs "" > $P/pmc_mfma_b1024_bench.json 2> $P/pmc_mfma_b1024.err
 python3 tools/pmc_mfma_summary.py $P/pmc_mfma_b1024 30 > $P/pmc_mfma_b1024.json
+unset DSM_GRAPHS
+# where the time goes at the capacity batch, the other two BASELINE configurations, and the co-run probes
+X=$P/extra
+mkdir -p $X
+C="python bench.py --batch 2048 --fast-fill --steps 12 --warmup 3 --no-cpu-baseline --capacity-legs ''"
+step b2048_all 200 bash -c "$C > $X/b2048_all.json 2> $X/b2048_all.err"
+step b2048_lm 200 bash -c "$C --part lm > $X/b2048_lm.json 2> $X/b2048_lm.err"
+step b2048_enc 200 bash -c "$C --part enc > $X/b2048_enc.json 2> $X/b2048_enc.err"
+step b2048_lm_g1 200 bash -c "DSM_LM_GROUPS=1 $C --part lm > $X/b2048_lm_one_group.json 2> $X/b2048_lm_g1.err"
+step b2048_1s 200 bash -c "$C --no-overlap > $X/b2048_single_stream.json 2> $X/b2048_1s.err"
+step b26 300 bash -c "python bench.py --config stt-2.6b-en --batch 128 --fast-fill --steps 50 --warmup 5 --no-cpu-baseline --capacity-legs '' > $X/bench_stt_2.6b_b128.json 2> $X/b26.err"
+step tts 200 bash -c "python bench.py --workload tts --batch 32 --steps 50 --warmup 5 --no-cpu-baseline --capacity-legs '' > $X/bench_tts_b32.json 2> $X/tts.err"
+if [ -x experiments/corun_probe ]; then step corun 200 bash -c "./experiments/corun_probe 8192 > $X/corun_probe.txt 2>&1"; fi
+if [ -x experiments/queue_probe ]; then step queue 100 bash -c "./experiments/queue_probe > $X/queue_probe.txt 2>&1"; fi
 python3 tools/trace_summary.py $P/trace_1stream 14
-ls $P
+ls $P $X
