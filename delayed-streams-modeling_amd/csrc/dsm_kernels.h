@@ -1415,6 +1415,145 @@ __global__ void extra_heads_kernel(const float* __restrict__ eh /* [B][nh*dim] *
 }
 
 // ------------------------------------------------------------------------------------------
+// SEANet front end, fused (r02): the encoder's first three convs for one slot and 64 output frames in one workgroup —
+//   init conv (1 -> 64, k 7)  ->  [ELU -> conv k 3 (64 -> 32) -> ELU -> conv k 1 (32 -> 64)] + skip  ->  ELU
+// (core/seanet.rs:292-302 with SeaNetResnetBlock::step :140-150; core/conv.rs:335-367 for the carried frames).  As three
+// GEMM launches these layers move ~7 GB at the capacity batch for 65 GFLOP of work (K = 7 / 192 / 32, N = 64 / 32 / 64
+// over B x 1920 rows: 3.3 ms of a 69 ms step at B = 2048); here the 64-channel intermediates never leave LDS: the
+// workgroup reads 72 PCM samples and writes one [64][64] tile of the next conv's input.
+// Arithmetic is the GEMM path's, operation for operation (dsm_numerics.h):
+//   * init conv: K = 7 sits in lane group q = 0 of one 32-block, so the canonical chain is fmaf over taps 0..6 from +0
+//     (the zero-padded taps add +0 to an accumulator that is never -0), then + bias: VALU, no MFMA;
+//   * conv k 3: K = 192 = six 32-blocks of one chunk, v_mfma_f32_16x16x4_f32 in the canonical order
+//     (k = 32 blk + 8 q + s, s outer), + bias, ELU; its im2col rows are windows of the ELU'd tile in LDS;
+//   * conv k 1: one 32-block, + bias, skip + value (the raw init-conv output, kept in LDS), ELU.
+// Carried frames: the k-3 conv's two past frames are read from its concat buffer's prefix (written by
+// conv_state_shift_kernel after the previous step) by the first tile of a slot; the last tile leaves the slot's two newest
+// ELU'd frames in that buffer's tail for the shift to carry.  The buffers in between (raw init output, the k-1 conv's
+// input) are not written at all.
+// ------------------------------------------------------------------------------------------
+struct SeanetFrontArgs {
+  const float* cat_init;  // [B][S0 + T] PCM with S0 = 6 carried samples in front
+  const float *w0, *b0;   // [64][ld0] (7 taps used), bias or null
+  const float *w1, *b1;   // [32][ld1], k = tap * 64 + channel
+  const float *w2, *b2;   // [64][ld2]
+  float* cat_ra;          // [B][2 + T][64]: ELU'd init output as the k-3 conv sees it (prefix read, tail written)
+  float* cat_down;        // [B][Sd + T][64]: the strided conv's concat buffer, rows Sd.. written
+  int ld0, ld1, ld2;
+  int T, S0, Sd;
+};
+
+__global__ __launch_bounds__(256) void seanet_front_kernel(SeanetFrontArgs a) {
+  constexpr int C0 = 64, C1 = 32, TAPS0 = 7, TM = 64;  // channels, init-conv taps, frames per workgroup
+  __shared__ float xs[TM + 2 + TAPS0 - 1];
+  __shared__ float w0s[C0 * TAPS0], b0s[C0];
+  __shared__ __attribute__((aligned(16))) float e0[(TM + 2) * C0];  // ELU(init conv), frames t0-2 .. t0+63; 16-byte unit u of row R at u ^ (R & 15)
+  __shared__ __attribute__((aligned(16))) float y0[TM * C0];        // raw init conv (the skip), same swizzle
+  __shared__ __attribute__((aligned(16))) float hs[TM * C1];        // ELU(conv k 3 + bias): the k-1 conv's activation block (dsm_xs_sw swizzle)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int b = blockIdx.y, t0 = blockIdx.x * TM;
+  const bool first = t0 == 0, last = t0 + TM == a.T;
+  const float* cat = a.cat_init + (long)b * (a.S0 + a.T);
+  // e0 row R (frame t0 - 2 + R) needs cat[t0 - 2 + R + s], s = 0..6
+  for (int i = tid; i < TM + 2 + TAPS0 - 1; i += 256) {
+    const int c = t0 - 2 + i;
+    xs[i] = c >= 0 ? cat[c] : 0.0f;  // c < 0 only feeds rows 0 and 1 of the first tile, which come from the carried frames
+  }
+  for (int i = tid; i < C0 * TAPS0; i += 256) w0s[i] = a.w0[(i / TAPS0) * a.ld0 + (i % TAPS0)];
+  if (tid < C0) b0s[tid] = a.b0 ? a.b0[tid] : 0.0f;
+  __syncthreads();
+  // ---- init conv + ELU (VALU): item = (row R, four channels) ----
+  for (int item = tid; item < (TM + 2) * (C0 / 4); item += 256) {
+    const int R = item >> 4, cq = item & 15;
+    float4 ev;
+    if (first && R < 2) {
+      ev = *reinterpret_cast<const float4*>(a.cat_ra + ((long)b * (2 + a.T) + R) * C0 + 4 * cq);
+    } else {
+      float yv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = 4 * cq + j;
+        float acc = 0.0f;
+#pragma unroll
+        for (int sidx = 0; sidx < TAPS0; ++sidx) acc = DSM_FMAF(w0s[c * TAPS0 + sidx], xs[R + sidx], acc);
+        yv[j] = a.b0 ? acc + b0s[c] : acc;
+      }
+      ev = make_float4(dsm_elu(yv[0]), dsm_elu(yv[1]), dsm_elu(yv[2]), dsm_elu(yv[3]));
+      if (R >= 2) *reinterpret_cast<float4*>(&y0[(R - 2) * C0 + 4 * (cq ^ ((R - 2) & 15))]) = make_float4(yv[0], yv[1], yv[2], yv[3]);
+      if (last && R >= TM)  // frames T-2, T-1: what conv_state_shift_kernel carries into the next step
+        *reinterpret_cast<float4*>(a.cat_ra + ((long)b * (2 + a.T) + 2 + (t0 - 2 + R)) * C0 + 4 * cq) = ev;
+    }
+    *reinterpret_cast<float4*>(&e0[R * C0 + 4 * (cq ^ (R & 15))]) = ev;
+  }
+  __syncthreads();
+  // ---- conv k 3: [64 frames][K = 192] x [32][192]^T; wave -> (n-tile wave & 1, m-tiles 2 (wave >> 1) + {0, 1}) ----
+  {
+    const int nt = wave & 1, mh = wave >> 1;
+    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    const float* wrow = a.w1 + (long)(16 * nt + r) * a.ld1 + 8 * q;
+#pragma unroll
+    for (int blk = 0; blk < 6; ++blk) {
+      float wa[8], xb[2][8];
+      load_w8<float>(wrow + 32 * blk, wa);
+      const int tap = blk >> 1, u0 = (blk & 1) * 8 + 2 * q;  // k = 32 blk + 8 q: tap k / 64, channel k % 64
+#pragma unroll
+      for (int m2 = 0; m2 < 2; ++m2) {
+        const int R = 16 * (2 * mh + m2) + r + tap;
+        const float4 f0 = *reinterpret_cast<const float4*>(&e0[R * C0 + 4 * (u0 ^ (R & 15))]);
+        const float4 f1 = *reinterpret_cast<const float4*>(&e0[R * C0 + 4 * ((u0 + 1) ^ (R & 15))]);
+        xb[m2][0] = f0.x; xb[m2][1] = f0.y; xb[m2][2] = f0.z; xb[m2][3] = f0.w;
+        xb[m2][4] = f1.x; xb[m2][5] = f1.y; xb[m2][6] = f1.z; xb[m2][7] = f1.w;
+      }
+#pragma unroll
+      for (int sidx = 0; sidx < 8; ++sidx)
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2) acc[m2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[sidx], xb[m2][sidx], acc[m2], 0, 0, 0);
+    }
+#pragma unroll
+    for (int m2 = 0; m2 < 2; ++m2) {
+      const int m = 16 * (2 * mh + m2) + r, n = 16 * nt + 4 * q;  // the lane holds channels n..n+3 of frame m
+      float o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = dsm_elu(a.b1 ? acc[m2][i] + a.b1[n + i] : acc[m2][i]);
+      *reinterpret_cast<float4*>(&hs[m * C1 + 4 * ((n >> 2) ^ dsm_xs_sw(m))]) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+  __syncthreads();
+  // ---- conv k 1 + skip + ELU: [64 frames][32] x [64][32]^T; wave -> n-tile `wave`, all four m-tiles ----
+  {
+    f32x4 acc[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float wa[8], xb[4][8];
+    load_w8<float>(a.w2 + (long)(16 * wave + r) * a.ld2 + 8 * q, wa);
+    const int xu0 = 4 * ((2 * q) ^ dsm_xs_sw(r)), xu1 = xu0 ^ 4;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const float* fp = &hs[(16 * mt + r) * C1];
+      const float4 f0 = *reinterpret_cast<const float4*>(fp + xu0), f1 = *reinterpret_cast<const float4*>(fp + xu1);
+      xb[mt][0] = f0.x; xb[mt][1] = f0.y; xb[mt][2] = f0.z; xb[mt][3] = f0.w;
+      xb[mt][4] = f1.x; xb[mt][5] = f1.y; xb[mt][6] = f1.z; xb[mt][7] = f1.w;
+    }
+#pragma unroll
+    for (int sidx = 0; sidx < 8; ++sidx)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[sidx], xb[mt][sidx], acc[mt], 0, 0, 0);
+    float* out = a.cat_down + ((long)b * (a.Sd + a.T) + a.Sd + t0) * C0;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int m = 16 * mt + r, n = 16 * wave + 4 * q;
+      const float4 rv = *reinterpret_cast<const float4*>(&y0[m * C0 + 4 * ((n >> 2) ^ (m & 15))]);
+      float o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = a.b2 ? acc[mt][i] + a.b2[n + i] : acc[mt][i];
+      o[0] = rv.x + o[0]; o[1] = rv.y + o[1]; o[2] = rv.z + o[2]; o[3] = rv.w + o[3];
+      *reinterpret_cast<float4*>(out + (long)m * C0 + n) = make_float4(dsm_elu(o[0]), dsm_elu(o[1]), dsm_elu(o[2]), dsm_elu(o[3]));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Streaming-conv state: in-place shift of the consumer's concat buffer after it ran
 // (core/conv.rs:335-367).  desc[i] = {ptr, state_len S, step frames T, channels C, batch stride}.
 // active slots: cat[b][0..S) = cat[b][T..T+S); inactive: unchanged (zeroed on the first call).

@@ -54,6 +54,38 @@ def test_full_size_encode_lm_and_decode(gpu, dsm, lib, orc, full_weights, monkey
     ora.close()
 
 
+@pytest.mark.parametrize("fuse_front", ["1", "0"])
+def test_seanet_front_fused_and_as_three_launches(gpu, dsm, lib, orc, full_weights, monkeypatch, fuse_front):
+    """The real Mimi front end — init conv (1 -> 64, k 7), residual block (64 -> 32 k 3 -> 64 k 1, skip) — runs as one kernel
+    with its intermediates in LDS (`seanet_front_kernel`, default) or as three GEMM launches (DSM_FUSE_FRONT=0): both must give
+    the oracle's latents and codes bit for bit over several frames (carried conv frames cross every frame boundary: the fused
+    kernel reads them from the k-3 conv's buffer prefix and leaves the newest two frames in its tail), with a paused slot whose
+    carried frames must not move, a mid-stream reset, and B = 5 so that tiles of different slots interleave."""
+    from dsm_amd import synth
+    cfg, (lm, mimi) = full_weights
+    monkeypatch.setenv("DSM_FUSE_FRONT", fuse_front)
+    B, steps = 5, 5
+    eng = dsm.AsrEngine(cfg, B, lm, mimi)
+    ora = orc.OracleAsr(cfg, B, lm, mimi)
+    pcm = synth.synth_pcm(B, steps, seed=31)
+    masks = np.ones((steps, B), dtype=np.uint8)
+    masks[1, 2] = 0
+    masks[2, 2] = 0
+    masks[3, 0] = 0
+    for s in range(steps):
+        if s == 3:
+            eng.mimi_reset_batch_idx(4); ora.mimi_reset_batch_idx(4, side=0)
+        act = masks[s].astype(bool)
+        ec = eng.encode_step(pcm[s], masks[s])
+        oc = ora.encode_step(pcm[s], masks[s])
+        lat_e = eng.debug_read("mimi.latent", B * cfg.mimi.dimension).reshape(B, -1)
+        lat_o = ora.debug_read("mimi.latent", B * cfg.mimi.dimension).reshape(B, -1)
+        assert np.array_equal(lat_e[act].view(np.uint32), lat_o[act].view(np.uint32)), f"latent differs at step {s}"
+        assert np.array_equal(ec[act], oc[act]), f"codes differ at step {s}"
+    eng.close()
+    ora.close()
+
+
 def test_stt_2_6b_en_shapes(gpu, dsm, lib, orc):
     """BASELINE.json configs[2]: stt-2.6b-en (48 layers, 32 heads x 64, ctx 375, vocab 4000, no extra heads)."""
     import os
