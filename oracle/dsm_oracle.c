@@ -1730,6 +1730,20 @@ int orc_mimi_reset_slot(orc_asr* a, int side, int slot) {
   return 0;
 }
 
+/* Test / bench hook, mirror of dsm_debug_set_positions: every slot's ring position is set as if `pos` frames had been
+ * appended (ScatteredCacheBuilder positions / indices, core/kv_cache.rs:57-59), for the LM and for both Mimi clones'
+ * encoder transformers.  The caches keep whatever they hold (zeros where nothing was written), exactly like the engine's. */
+int orc_debug_set_positions(orc_asr* a, uint32_t lm_pos, uint32_t mimi_pos) {
+  orc_kvb* k = a->lm->tr->builder;
+  for (int b = 0; b < k->B; ++b) { k->positions[b] = lm_pos; k->indices[b] = lm_pos % (uint32_t)k->context; }
+  for (int side = 0; side < 2; ++side) {
+    if (!a->mimi[side] || !a->mimi[side]->enc_tr) continue;
+    orc_kvb* m = a->mimi[side]->enc_tr->builder;
+    for (int b = 0; b < m->B; ++b) { m->positions[b] = mimi_pos; m->indices[b] = mimi_pos % (uint32_t)m->context; }
+  }
+  return 0;
+}
+
 int orc_asr_poll_msgs(orc_asr* a, dsm_asr_msg* msgs, int cap, uint32_t* tokens_out, int tokens_cap) {
   int n = MINI(cap, a->n_msgs);
   for (int i = 0; i < n; ++i) msgs[i] = a->msgs[i];

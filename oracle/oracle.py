@@ -38,6 +38,7 @@ def lib():
         L.orc_mimi_reset_slot.argtypes = [vp, C.c_int, C.c_int]
         L.orc_asr_poll_msgs.argtypes = [vp, C.POINTER(AsrMsg), C.c_int, vp, C.c_int]
         L.orc_debug_read.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
+        L.orc_debug_set_positions.argtypes = [vp, C.c_uint32, C.c_uint32]
         L.orc_set_num_threads.argtypes = [C.c_int]
         L.orc_set_num_threads.restype = None
         L.orc_dot.argtypes = [vp, vp, C.c_int]
@@ -193,6 +194,10 @@ class OracleAsr:
 
     def mimi_reset_batch_idx(self, slot, side=0):
         self.L.orc_mimi_reset_slot(self.h, side, slot)
+
+    def debug_set_positions(self, lm_pos, mimi_pos):
+        """Mirror of AsrEngine.debug_set_positions: every ring as if that many frames had been appended."""
+        self.L.orc_debug_set_positions(self.h, lm_pos, mimi_pos)
 
     def debug_read(self, name, n):
         out = np.zeros(n, dtype=np.float32)

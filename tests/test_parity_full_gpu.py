@@ -86,6 +86,42 @@ def test_seanet_front_fused_and_as_three_launches(gpu, dsm, lib, orc, full_weigh
     ora.close()
 
 
+def test_full_size_steady_state_wrapped_ring(gpu, dsm, lib, orc, full_weights):
+    """The benchmarked regime itself, at the real dimensions: every ring is jumped past its context (`debug_set_positions` on
+    both sides: 3 x 750 + 11 LM frames, 3 x 250 + 5 Mimi frames — wrapped, every one of the 750 / 250 slots visible, write
+    index mid-ring) and the engine is compared with the oracle on full-length attention — hd 128 bf16 with six pipelined
+    iterations per phase in the LM, hd 64 f32 T = 2 in Mimi — through frames that overwrite ring slots, with a paused slot and
+    the fused QKV prologue writing the new K/V row into a full ring.  Bits: latents, codes, LM hidden state, logits, tokens, VAD."""
+    from dsm_amd import synth
+    cfg, (lm, mimi) = full_weights
+    B, steps = 3, 3
+    eng = dsm.AsrEngine(cfg, B, lm, mimi)
+    ora = orc.OracleAsr(cfg, B, lm, mimi)
+    pcm = synth.synth_pcm(B, steps + 1, seed=41)
+    ones = np.ones(B, dtype=np.uint8)
+    # one ordinary frame first, so that ring rows 0.. hold real keys on both sides; the rest of the rings are zeros on both
+    ec, et, ep = eng.step_pcm(pcm[0], ones)
+    oc, ot, op = ora.step_pcm(pcm[0], ones)
+    assert np.array_equal(ec, oc) and np.array_equal(et, ot)
+    lm_pos, mimi_pos = 3 * cfg.lm.context + 11, 3 * cfg.mimi.transformer.context + 5
+    eng.debug_set_positions(lm_pos, mimi_pos)
+    ora.debug_set_positions(lm_pos, mimi_pos)
+    masks = np.ones((steps, B), dtype=np.uint8)
+    masks[1, 1] = 0
+    for s in range(steps):
+        act = masks[s].astype(bool)
+        ec, et, ep = eng.step_pcm(pcm[1 + s], masks[s])
+        oc, ot, op = ora.step_pcm(pcm[1 + s], masks[s])
+        for tap, n in (("mimi1.latent", cfg.mimi.dimension), ("lm.hidden", cfg.lm.d_model), ("lm.logits", cfg.text_out_vocab_size)):
+            ge = eng.debug_read(tap, B * n).reshape(B, -1)
+            go = ora.debug_read(tap, B * n).reshape(B, -1)
+            assert np.array_equal(ge[act].view(np.uint32), go[act].view(np.uint32)), f"{tap} differs at steady-state step {s}"
+        assert np.array_equal(ec[act], oc[act]) and np.array_equal(et[act], ot[act]), f"codes / tokens differ at step {s}"
+        assert np.array_equal(ep[:, act].view(np.uint32), op[:, act].view(np.uint32)), f"VAD differs at step {s}"
+    eng.close()
+    ora.close()
+
+
 def test_stt_2_6b_en_shapes(gpu, dsm, lib, orc):
     """BASELINE.json configs[2]: stt-2.6b-en (48 layers, 32 heads x 64, ctx 375, vocab 4000, no extra heads)."""
     import os
