@@ -81,3 +81,42 @@ def test_large_batch_slots_with_equal_audio_agree_and_match_b4(gpu, dsm, lib, B)
         assert np.array_equal(pb.view(np.uint32), ps[:, owner].view(np.uint32)), f"steady step {s}: VAD differs"
     big.close()
     small.close()
+
+
+def test_tts_b384_slots_with_equal_inputs_agree_and_match_b3(gpu, dsm, lib):
+    """The same property for the TTS step (BASELINE.json configs[4] shapes; B = 32 is the oracle-compared size): at B = 384 the
+    main LM runs its 64-row whole-K loop kernels and 6144-workgroup attention launches, the depformer 32 slices of M = 384
+    GEMMs with a 384-row argmax / top-k.  Slots fed the same text stream, allowed-token rule, mask and sampling seed must
+    generate the same text and audio tokens and the same LM hidden state as a B = 3 engine — argmax slots and seeded
+    top-k slots alike, through a paused step."""
+    from dsm_amd import synth
+    cfg = dsm.config_tts_v202501()
+    cfg.text_audio_delay_in_tokens, cfg.max_steps = 0, 32  # depformer live from the first step
+    path = synth.make_synth_tts_weights(cfg, WEIGHTS_DIR, tag="tts-v202501-prop")
+    B, NS, steps = 384, 3, 5
+    rng = np.random.default_rng(13)
+    owner = rng.integers(0, NS, B)
+    owner[[0, 1, 2, 191, 192, 193, 381, 382, 383]] = [0, 1, 2, 0, 1, 2, 0, 1, 2]
+    prev_src = rng.integers(0, cfg.text_in_vocab_size, (steps, NS)).astype(np.uint32)
+    allowed_src = np.stack([np.array([int(rng.integers(4, 8000)), dsm.TTS_ALLOW_PAD_OR_EPAD, int(rng.integers(4, 8000))], dtype=np.int32)
+                            for _ in range(steps)])
+    mask_src = np.ones((steps, NS), dtype=np.uint8)
+    mask_src[2, 1] = 0
+    small = dsm.TtsEngine(cfg, NS, path)
+    big = dsm.TtsEngine(cfg, B, path)
+    small.set_sampling(2, 50, 0.8, 1234)          # source stream 2 samples (top-k 50, T 0.8), streams 0 and 1 take the argmax
+    for b in np.nonzero(owner == 2)[0]:
+        big.set_sampling(int(b), 50, 0.8, 1234)
+    for s in range(steps):
+        ts, as_ = small.step(prev_src[s], allowed_src[s], mask_src[s])
+        hs = small.debug_read("lm.hidden", NS * cfg.lm.d_model).reshape(NS, -1).copy()
+        mask = np.ascontiguousarray(mask_src[s][owner])
+        tb, ab = big.step(np.ascontiguousarray(prev_src[s][owner]), np.ascontiguousarray(allowed_src[s][owner]), mask)
+        hb = big.debug_read("lm.hidden", B * cfg.lm.d_model).reshape(B, -1)
+        act = mask.astype(bool)
+        assert np.array_equal(tb[act], ts[owner][act]), f"text tokens of a B={B} slot differ from the same stream at B={NS}, step {s}"
+        assert np.array_equal(ab[act], as_[owner][act]), f"depformer tokens differ, step {s}"
+        assert np.array_equal(hb[act].view(np.uint32), hs[owner][act].view(np.uint32)), f"LM hidden state differs, step {s}"
+    big.close()
+    small.close()
+    os.remove(path)
