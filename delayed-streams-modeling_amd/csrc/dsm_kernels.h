@@ -1443,11 +1443,12 @@ struct SeanetFrontArgs {
   int T, S0, Sd;
 };
 
+template <int TM>  // frames per workgroup: 64 or 32 (smaller tiles: more workgroups per CU to hide the three phases behind each other)
 __global__ __launch_bounds__(256) void seanet_front_kernel(SeanetFrontArgs a) {
-  constexpr int C0 = 64, C1 = 32, TAPS0 = 7, TM = 64;  // channels, init-conv taps, frames per workgroup
+  constexpr int C0 = 64, C1 = 32, TAPS0 = 7, MTILES = TM / 16;
+  static_assert(TM == 64 || TM == 32, "tile");
   __shared__ float xs[TM + 2 + TAPS0 - 1];
-  __shared__ float w0s[C0 * TAPS0], b0s[C0];
-  __shared__ __attribute__((aligned(16))) float e0[(TM + 2) * C0];  // ELU(init conv), frames t0-2 .. t0+63; 16-byte unit u of row R at u ^ (R & 15)
+  __shared__ __attribute__((aligned(16))) float e0[(TM + 2) * C0];  // ELU(init conv), frames t0-2 .. t0+TM-1; 16-byte unit u of row R at u ^ (R & 15)
   __shared__ __attribute__((aligned(16))) float y0[TM * C0];        // raw init conv (the skip), same swizzle
   __shared__ __attribute__((aligned(16))) float hs[TM * C1];        // ELU(conv k 3 + bias): the k-1 conv's activation block (dsm_xs_sw swizzle)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1460,24 +1461,31 @@ __global__ __launch_bounds__(256) void seanet_front_kernel(SeanetFrontArgs a) {
     const int c = t0 - 2 + i;
     xs[i] = c >= 0 ? cat[c] : 0.0f;  // c < 0 only feeds rows 0 and 1 of the first tile, which come from the carried frames
   }
-  for (int i = tid; i < C0 * TAPS0; i += 256) w0s[i] = a.w0[(i / TAPS0) * a.ld0 + (i % TAPS0)];
-  if (tid < C0) b0s[tid] = a.b0 ? a.b0[tid] : 0.0f;
+  // ---- init conv + ELU (VALU): a thread keeps its four channels' taps and biases in registers and walks rows tid / 16 + 16 i ----
+  const int cq = tid & 15;
+  float w0r[4][TAPS0], b0r[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+#pragma unroll
+    for (int sidx = 0; sidx < TAPS0; ++sidx) w0r[j][sidx] = a.w0[(long)(4 * cq + j) * a.ld0 + sidx];
+    b0r[j] = a.b0 ? a.b0[4 * cq + j] : 0.0f;
+  }
   __syncthreads();
-  // ---- init conv + ELU (VALU): item = (row R, four channels) ----
-  for (int item = tid; item < (TM + 2) * (C0 / 4); item += 256) {
-    const int R = item >> 4, cq = item & 15;
+  for (int R = tid >> 4; R < TM + 2; R += 16) {
     float4 ev;
     if (first && R < 2) {
       ev = *reinterpret_cast<const float4*>(a.cat_ra + ((long)b * (2 + a.T) + R) * C0 + 4 * cq);
     } else {
+      float xr[TAPS0];
+#pragma unroll
+      for (int sidx = 0; sidx < TAPS0; ++sidx) xr[sidx] = xs[R + sidx];
       float yv[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int c = 4 * cq + j;
         float acc = 0.0f;
 #pragma unroll
-        for (int sidx = 0; sidx < TAPS0; ++sidx) acc = DSM_FMAF(w0s[c * TAPS0 + sidx], xs[R + sidx], acc);
-        yv[j] = a.b0 ? acc + b0s[c] : acc;
+        for (int sidx = 0; sidx < TAPS0; ++sidx) acc = DSM_FMAF(w0r[j][sidx], xr[sidx], acc);
+        yv[j] = a.b0 ? acc + b0r[j] : acc;
       }
       ev = make_float4(dsm_elu(yv[0]), dsm_elu(yv[1]), dsm_elu(yv[2]), dsm_elu(yv[3]));
       if (R >= 2) *reinterpret_cast<float4*>(&y0[(R - 2) * C0 + 4 * (cq ^ ((R - 2) & 15))]) = make_float4(yv[0], yv[1], yv[2], yv[3]);
@@ -1487,19 +1495,23 @@ __global__ __launch_bounds__(256) void seanet_front_kernel(SeanetFrontArgs a) {
     *reinterpret_cast<float4*>(&e0[R * C0 + 4 * (cq ^ (R & 15))]) = ev;
   }
   __syncthreads();
-  // ---- conv k 3: [64 frames][K = 192] x [32][192]^T; wave -> (n-tile wave & 1, m-tiles 2 (wave >> 1) + {0, 1}) ----
+  // ---- conv k 3: [TM frames][K = 192] x [32][192]^T.  TM = 64: wave -> (n-tile wave & 1, m-tiles 2 (wave >> 1) + {0, 1});
+  //      TM = 32: wave -> (n-tile wave & 1, m-tile wave >> 1) ----
   {
+    constexpr int MPW = MTILES / 2;  // m-tiles per wave
     const int nt = wave & 1, mh = wave >> 1;
-    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    f32x4 acc[MPW];
+#pragma unroll
+    for (int m2 = 0; m2 < MPW; ++m2) acc[m2] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float* wrow = a.w1 + (long)(16 * nt + r) * a.ld1 + 8 * q;
 #pragma unroll
     for (int blk = 0; blk < 6; ++blk) {
-      float wa[8], xb[2][8];
+      float wa[8], xb[MPW][8];
       load_w8<float>(wrow + 32 * blk, wa);
       const int tap = blk >> 1, u0 = (blk & 1) * 8 + 2 * q;  // k = 32 blk + 8 q: tap k / 64, channel k % 64
 #pragma unroll
-      for (int m2 = 0; m2 < 2; ++m2) {
-        const int R = 16 * (2 * mh + m2) + r + tap;
+      for (int m2 = 0; m2 < MPW; ++m2) {
+        const int R = 16 * (MPW * mh + m2) + r + tap;
         const float4 f0 = *reinterpret_cast<const float4*>(&e0[R * C0 + 4 * (u0 ^ (R & 15))]);
         const float4 f1 = *reinterpret_cast<const float4*>(&e0[R * C0 + 4 * ((u0 + 1) ^ (R & 15))]);
         xb[m2][0] = f0.x; xb[m2][1] = f0.y; xb[m2][2] = f0.z; xb[m2][3] = f0.w;
@@ -1508,11 +1520,11 @@ __global__ __launch_bounds__(256) void seanet_front_kernel(SeanetFrontArgs a) {
 #pragma unroll
       for (int sidx = 0; sidx < 8; ++sidx)
 #pragma unroll
-        for (int m2 = 0; m2 < 2; ++m2) acc[m2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[sidx], xb[m2][sidx], acc[m2], 0, 0, 0);
+        for (int m2 = 0; m2 < MPW; ++m2) acc[m2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[sidx], xb[m2][sidx], acc[m2], 0, 0, 0);
     }
 #pragma unroll
-    for (int m2 = 0; m2 < 2; ++m2) {
-      const int m = 16 * (2 * mh + m2) + r, n = 16 * nt + 4 * q;  // the lane holds channels n..n+3 of frame m
+    for (int m2 = 0; m2 < MPW; ++m2) {
+      const int m = 16 * (MPW * mh + m2) + r, n = 16 * nt + 4 * q;  // the lane holds channels n..n+3 of frame m
       float o[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) o[i] = dsm_elu(a.b1 ? acc[m2][i] + a.b1[n + i] : acc[m2][i]);
@@ -1520,16 +1532,16 @@ __global__ __launch_bounds__(256) void seanet_front_kernel(SeanetFrontArgs a) {
     }
   }
   __syncthreads();
-  // ---- conv k 1 + skip + ELU: [64 frames][32] x [64][32]^T; wave -> n-tile `wave`, all four m-tiles ----
+  // ---- conv k 1 + skip + ELU: [TM frames][32] x [64][32]^T; wave -> n-tile `wave`, every m-tile ----
   {
-    f32x4 acc[4];
+    f32x4 acc[MTILES];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float wa[8], xb[4][8];
+    for (int mt = 0; mt < MTILES; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float wa[8], xb[MTILES][8];
     load_w8<float>(a.w2 + (long)(16 * wave + r) * a.ld2 + 8 * q, wa);
     const int xu0 = 4 * ((2 * q) ^ dsm_xs_sw(r)), xu1 = xu0 ^ 4;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
+    for (int mt = 0; mt < MTILES; ++mt) {
       const float* fp = &hs[(16 * mt + r) * C1];
       const float4 f0 = *reinterpret_cast<const float4*>(fp + xu0), f1 = *reinterpret_cast<const float4*>(fp + xu1);
       xb[mt][0] = f0.x; xb[mt][1] = f0.y; xb[mt][2] = f0.z; xb[mt][3] = f0.w;
@@ -1538,10 +1550,10 @@ __global__ __launch_bounds__(256) void seanet_front_kernel(SeanetFrontArgs a) {
 #pragma unroll
     for (int sidx = 0; sidx < 8; ++sidx)
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[sidx], xb[mt][sidx], acc[mt], 0, 0, 0);
+      for (int mt = 0; mt < MTILES; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[sidx], xb[mt][sidx], acc[mt], 0, 0, 0);
     float* out = a.cat_down + ((long)b * (a.Sd + a.T) + a.Sd + t0) * C0;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
+    for (int mt = 0; mt < MTILES; ++mt) {
       const int m = 16 * mt + r, n = 16 * wave + 4 * q;
       const float4 rv = *reinterpret_cast<const float4*>(&y0[m * C0 + 4 * ((n >> 2) ^ (m & 15))]);
       float o[4];
