@@ -14,6 +14,13 @@ dev = torch.device("cuda", 0)
 Bs = [int(x) for x in sys.argv[1:]] or [512, 2048]
 KNOBS = [
     {},                                            # defaults: rolling window depth 4, 2 groups, graphs, staggered start from 256 slots per group
+    {"DSM_STAGGER": "0"},
+    {"DSM_LM_GROUPS": "4"},
+    {"DSM_ATTN_LDS_PAD": "45000"},                 # three attention workgroups per CU instead of two
+    {"DSM_ATTN_LDS_PAD": "0"},
+    {"DSM_FUSE_FRONT": "0"},
+    {"DSM_SMALLK_LOOP": "0"},
+    {"DSM_ROLL": "0"},
 ]
 for B in Bs:
     for kn in KNOBS:
