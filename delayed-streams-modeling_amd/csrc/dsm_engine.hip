@@ -195,6 +195,7 @@ struct dsm_engine {
   bool gate_occ3 = false;     // DSM_GATE_OCC3=1: the gate's whole-K kernel squeezed to 168 VGPRs (three waves per SIMD, 80 B of spills)
   int loop_depth = 4;         // DSM_LOOP_DEPTH=2: two-block rolling window (fewer registers, three waves per SIMD) where four is the default
   size_t attn_lds_pad = 60000;  // DSM_ATTN_LDS_PAD: extra dynamic LDS per attention workgroup of a large launch (2 per CU)
+  int attn_nt = 1;            // DSM_ATTN_NT: ring-cache rows with non-temporal loads: 0 never, 1 bf16 rings (default), 2 every ring
   bool fuse_front = true;     // DSM_FUSE_FRONT=0: the SEANet front end as three GEMM launches (r01)
   int smallk_loop = 1;        // DSM_SMALLK_LOOP=0: one-chunk GEMMs (K <= 256) over many m-tiles stay on gemm_tile_kernel (r01)
   int smallk_min_tiles = 1024;  // DSM_SMALLK_MIN: from how many 64-row tiles on

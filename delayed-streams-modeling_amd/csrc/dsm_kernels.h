@@ -114,10 +114,18 @@ __device__ __forceinline__ void load_w8<float>(const float* p, float (&o)[8]) {
 // 8 consecutive cache elements kept as raw words until they are used (prefetch registers of the attention kernel)
 template <typename KVT>
 struct Raw8;
+typedef unsigned int dsm_u32x4 __attribute__((ext_vector_type(4)));
+typedef float dsm_f32x4v __attribute__((ext_vector_type(4)));
 template <>
 struct Raw8<uint16_t> {
   uint4 v;
   __device__ __forceinline__ void load(const uint16_t* p) { v = *reinterpret_cast<const uint4*>(p); }
+  // non-temporal: a ring cache is read once per step and is far larger than the Infinity Cache — do not let it evict the
+  // weights the other stream group is about to read again
+  __device__ __forceinline__ void load_nt(const uint16_t* p) {
+    const dsm_u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const dsm_u32x4*>(p));
+    v = make_uint4(t[0], t[1], t[2], t[3]);
+  }
   __device__ __forceinline__ void unpack(float (&o)[8]) const {
     o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xFFFF0000u);
     o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xFFFF0000u);
@@ -131,6 +139,12 @@ struct Raw8<float> {
   __device__ __forceinline__ void load(const float* p) {
     a = *reinterpret_cast<const float4*>(p);
     b = *reinterpret_cast<const float4*>(p + 4);
+  }
+  __device__ __forceinline__ void load_nt(const float* p) {
+    const dsm_f32x4v t0 = __builtin_nontemporal_load(reinterpret_cast<const dsm_f32x4v*>(p));
+    const dsm_f32x4v t1 = __builtin_nontemporal_load(reinterpret_cast<const dsm_f32x4v*>(p + 4));
+    a = make_float4(t0[0], t0[1], t0[2], t0[3]);
+    b = make_float4(t1[0], t1[1], t1[2], t1[3]);
   }
   __device__ __forceinline__ void unpack(float (&o)[8]) const {
     o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
@@ -926,6 +940,7 @@ struct AttnFused {
   int chunks;
   const float* rope_cs;
   const uint32_t* widx;
+  int nt;  // K / V rows with non-temporal loads (DSM_ATTN_NT)
 };
 
 template <typename KVT, int HD, int T>
@@ -1014,7 +1029,8 @@ __global__ __launch_bounds__(256, 4) void attn_kernel(float* __restrict__ out, c
 #define DSM_ISSUE(R, BASE, J0)                                                        \
   _Pragma("unroll") for (int u = 0; u < UNR; ++u) {                                    \
     const int jj = min((J0) + u * NW * G + g, jlast);                                  \
-    R[u].load(BASE + (long)jj * HD + 8 * li);                                          \
+    if (fq.nt) R[u].load_nt(BASE + (long)jj * HD + 8 * li);                            \
+    else R[u].load(BASE + (long)jj * HD + 8 * li);                                     \
   }
 #define DSM_SCORES(R, J0)                                                              \
   _Pragma("unroll") for (int u = 0; u < UNR; ++u) {                                    \
