@@ -35,13 +35,15 @@ def _run(eng, cfg, B, pcm, masks, reset_at, reset_slots, taps):
     return out
 
 
-@pytest.mark.parametrize("B", [1024, 2304])
-def test_large_batch_slots_with_equal_audio_agree_and_match_b4(gpu, dsm, lib, B):
+@pytest.mark.parametrize("model,B", [("stt-1b-en_fr", 1024), ("stt-1b-en_fr", 2304), ("stt-2.6b-en", 512)])
+def test_large_batch_slots_with_equal_audio_agree_and_match_b4(gpu, dsm, lib, model, B):
     """B = 2304 adds what only the capacity legs run: 18 m-tiles per group in the whole-K loop kernels, the RVQ distance GEMMs
-    and the first SEANet layers on the one-chunk loop path (>= 1024 m-tiles), 227 GB of ring cache."""
+    and the first SEANet layers on the one-chunk loop path (>= 1024 m-tiles), 227 GB of ring cache.  stt-2.6b-en at B = 512
+    (BASELINE.json configs[2] is quoted at 128): 48 layers, 32 heads x 64 — the bf16 hd-64 attention with non-temporal loads
+    on 8192-workgroup launches, K = 2048 / 8192 loop GEMMs over 4 m-tiles per group."""
     from dsm_amd import synth
-    cfg = dsm.config_stt_1b_en_fr()
-    lm, mimi = synth.make_synth_weights(cfg, WEIGHTS_DIR, tag="stt-1b-en_fr")
+    cfg = dsm.config_stt_1b_en_fr() if model == "stt-1b-en_fr" else dsm.config_stt_2_6b_en()
+    lm, mimi = synth.make_synth_weights(cfg, WEIGHTS_DIR, tag=model)
     NS, steps = 4, 4
     rng = np.random.default_rng(21)
     src_pcm = synth.synth_pcm(NS, steps, seed=77)                  # [steps][NS][1920]
