@@ -106,7 +106,8 @@ class Metrics(C.Structure):
     _fields_ = [("last_encode_us", C.c_double), ("last_lm_us", C.c_double),
                 ("algorithmic_bytes_encode", C.c_double), ("algorithmic_bytes_lm", C.c_double),
                 ("steps_encode", C.c_uint64), ("steps_lm", C.c_uint64),
-                ("graph_launches", C.c_uint64), ("eager_bodies", C.c_uint64)]
+                ("graph_launches", C.c_uint64), ("eager_bodies", C.c_uint64),
+                ("capture_failures", C.c_uint64), ("capture_error", C.c_char * 96)]
 
 
 MSG_STEP, MSG_WORD, MSG_END_WORD = 0, 1, 2

@@ -240,14 +240,26 @@ struct dsm_engine {
     hipGraphExec_t exec = nullptr;
     uint64_t key = 0, ws_gen = 0;
     int warm = 0;
+    int failures = 0;  // captures of this sequence that did not end in a graph; after kMaxCaptureTries it stays eager
     bool disabled = false;
   };
+  static constexpr int kMaxCaptureTries = 3;
   bool use_graphs = true;
   // capturing: per host thread (the encoder thread may capture while the model thread launches eagerly)
   static thread_local bool capturing;
   bool capture_failed = false;
   GraphSlot g_enc[2], g_grp[kMaxGroups], g_dec, g_tts[2];
-  std::atomic<uint64_t> graph_launches{0}, eager_bodies{0};
+  std::atomic<uint64_t> graph_launches{0}, eager_bodies{0}, capture_failures{0};
+  std::string capture_error;  // what the first failed capture reported (err_mu)
+  // a capture that did not produce a graph is never silent: counted, its first reason kept for dsm_metrics
+  void note_capture_failure(const char* what, hipError_t he) {
+    capture_failures += 1;
+    std::lock_guard<std::mutex> lk(err_mu);
+    if (capture_error.empty()) {
+      capture_error = what;
+      if (he != hipSuccess) { capture_error += ": "; capture_error += hipGetErrorString(he); }
+    }
+  }
   // run-ahead pipeline between the encoder thread and the model thread (dsm_mimi_encode_step_async /
   // dsm_asr_step_tokens_ticket): the reference's sync_channel(100) of PipelineMsg (srv/batched_asr.rs:291), here a ring of
   // kPipe frames: pinned staging for the PCM + mask, a private device copy of the frame's codes, one event "encoded" and
@@ -264,12 +276,14 @@ struct dsm_engine {
   int pipe_next = 0;
   bool pipe_ready = false;
   std::mutex pipe_mu;
-  // Two host threads may drive one engine (dsm_mimi_encode_step_async / dsm_asr_step_tokens_ticket).  ROCm 7.2 now and then
-  // invalidates a stream capture ("operation failed due to a previous error during capture") while the process's OTHER
-  // thread is inside HIP calls of its own, in every capture mode — most likely its waits on events whose last record was
-  // on the stream that is capturing now (ev_consumed / ev_done), which the runtime then takes for captured events.  A
-  // capture therefore runs alone: the two entry points hold api_mu shared for the whole call, run_captured trades that
-  // for the exclusive side around Begin..Instantiate.
+  // Two host threads may drive one engine (encoder thread || model thread, srv/batched_asr.rs:314,432).  A stream capture
+  // must not see the OTHER thread touch the capturing stream or an event of it: the model thread's dsm_streams_join records
+  // ev_join ON the encoder stream and then makes the model stream wait for it — issued while the encoder thread is between
+  // Begin and EndCapture on that stream, the record lands inside the capture and the wait pulls the model stream into it
+  // (EndCapture then fails as "unjoined" / "invalidated", which is what r02 saw now and then); the same goes for
+  // hipEventSynchronize / hipStreamWaitEvent on ev_done / ev_consumed against a capture on the stream of their last record.
+  // A capture therefore runs alone: every entry point that issues HIP work holds api_mu shared for the whole call,
+  // run_captured trades that for the exclusive side around Begin..Instantiate (a few times per engine lifetime).
   std::shared_mutex api_mu;
   static thread_local std::shared_lock<std::shared_mutex>* api_held;
   // per-kernel-class event timing (dsm_prof_*)
@@ -408,11 +422,19 @@ struct dsm_engine {
 thread_local bool dsm_engine::capturing = false;
 thread_local std::shared_lock<std::shared_mutex>* dsm_engine::api_held = nullptr;
 
-// shared side of dsm_engine::api_mu for the length of one API call on a two-thread entry point
+// shared side of dsm_engine::api_mu for the length of one API call: EVERY entry point that issues HIP work holds it (r03;
+// r02 had it on the two ticket entry points only, and the synchronous pair dsm_mimi_encode_step || dsm_asr_step_tokens of
+// tests/harness ran unprotected).  Nested entry points (one public call inside another on the same thread) share the outer hold.
 struct ApiShared {
   std::shared_lock<std::shared_mutex> lk;
-  explicit ApiShared(dsm_engine* e) : lk(e->api_mu) { dsm_engine::api_held = &lk; }
-  ~ApiShared() { dsm_engine::api_held = nullptr; }
+  bool outer;
+  explicit ApiShared(dsm_engine* e) : outer(dsm_engine::api_held == nullptr) {
+    if (outer) {
+      lk = std::shared_lock<std::shared_mutex>(e->api_mu);
+      dsm_engine::api_held = &lk;
+    }
+  }
+  ~ApiShared() { if (outer) dsm_engine::api_held = nullptr; }
 };
 // exclusive side, for a capture: gives up this thread's shared hold first (two threads upgrading at once would deadlock)
 struct ApiExclusive {
@@ -1016,30 +1038,37 @@ int run_captured(dsm_engine* e, dsm_engine::GraphSlot& gs, hipStream_t st, uint6
     if (gs.ws_gen != e->ws_gen) { gs.ws_gen = e->ws_gen; gs.warm = 0; }  // a workspace moved during this run
     return rc;
   }
-  // Relaxed mode: the body only launches kernels and async copies on `st`, and the host's OTHER thread (encoder vs model
-  // side) keeps calling synchronising APIs on its own streams meanwhile — under the thread-local mode ROCm 7.2 invalidated
-  // this capture when that happened (tests/test_worker_gpu.py, two-thread pipeline).
+  // Relaxed mode: the body only launches kernels and async copies on `st`; other threads are kept out by the API lock.
   ApiExclusive alone(e);
-  HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+  hipError_t hb = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
+  if (hb != hipSuccess) {
+    (void)hipGetLastError();
+    e->note_capture_failure("hipStreamBeginCapture", hb);
+    if (++gs.failures >= dsm_engine::kMaxCaptureTries) gs.disabled = true;
+    gs.warm = 0;
+    e->eager_bodies += 1;
+    return body();
+  }
   e->capturing = true;
   e->capture_failed = false;
   const int rc = body();
   e->capturing = false;
   hipGraph_t g = nullptr;
   const hipError_t he = hipStreamEndCapture(st, &g);
-  if (rc || he != hipSuccess || !g) {
-    if (g) (void)hipGraphDestroy(g);
-    (void)hipGetLastError();
-    gs.disabled = true;  // this body does not capture here: stay eager from now on
-    e->eager_bodies += 1;
-    return body();
-  }
-  const hipError_t hi = hipGraphInstantiate(&gs.exec, g, nullptr, nullptr, 0);
-  (void)hipGraphDestroy(g);
-  if (hi != hipSuccess) {
+  hipError_t hi = hipSuccess;
+  if (!rc && he == hipSuccess && g) hi = hipGraphInstantiate(&gs.exec, g, nullptr, nullptr, 0);
+  if (g) (void)hipGraphDestroy(g);
+  if (rc || he != hipSuccess || !g || hi != hipSuccess) {
+    // Never silent (r02 swallowed this and stayed eager for good): counted in dsm_metrics.capture_failures with the first
+    // reason kept, the body re-run launch by launch so that the step still happens, and the capture tried again after two
+    // more settled runs — up to kMaxCaptureTries times, then this sequence stays eager.
     gs.exec = nullptr;
-    gs.disabled = true;
     (void)hipGetLastError();
+    e->note_capture_failure(rc ? (e->capture_failed ? "workspace grew during capture" : "launch error during capture")
+                               : he != hipSuccess ? "hipStreamEndCapture" : !g ? "hipStreamEndCapture returned no graph" : "hipGraphInstantiate",
+                            rc ? hipSuccess : he != hipSuccess ? he : hi);
+    if (++gs.failures >= dsm_engine::kMaxCaptureTries) gs.disabled = true;
+    gs.warm = 0;
     e->eager_bodies += 1;
     return body();
   }

@@ -121,6 +121,9 @@ typedef struct dsm_metrics {
   uint64_t steps_lm;
   uint64_t graph_launches;   /* launch sequences replayed as one hipGraphLaunch (Mimi encode / decode, one LM stream group, one TTS step) */
   uint64_t eager_bodies;     /* the same sequences enqueued launch by launch (warm-up runs, DSM_GRAPHS=0, profiling on) */
+  uint64_t capture_failures; /* stream captures that were begun and did not end in a launchable graph (the body then ran launch by
+                                launch; the capture is retried up to three times before that sequence stays eager).  Expected: 0 */
+  char capture_error[96];    /* what the FIRST such failure reported (hipGetErrorString / the engine's own reason), "" if none */
 } dsm_metrics;
 
 /*

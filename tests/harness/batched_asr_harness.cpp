@@ -156,6 +156,18 @@ int main(int argc, char** argv) {
     });
     encoder.join();
     model.join();
+    // the launch-bound sequences must have been captured and replayed as hipGraphs with both threads inside the library, and no
+    // capture may have failed on the way (the old silent fallback to eager launches would have passed unnoticed)
+    dsm_metrics mt;
+    CHECK(dsm_get_metrics(e, &mt));
+    printf("graphs: %llu replays, %llu eager bodies, %llu capture failures%s%s\n", (unsigned long long)mt.graph_launches,
+           (unsigned long long)mt.eager_bodies, (unsigned long long)mt.capture_failures, mt.capture_failures ? ": " : "", mt.capture_error);
+    const char* genv = getenv("DSM_GRAPHS");
+    const bool graphs_on = !(genv && atoi(genv) == 0);
+    if (mt.capture_failures != 0 || (graphs_on && frames >= 8 && mt.graph_launches == 0)) {
+      fprintf(stderr, "graph capture did not hold under two threads\n");
+      return 4;
+    }
     dsm_destroy(e);
   }
 

@@ -5,6 +5,7 @@
 // Exit code 0 = every case was either decoded or rejected cleanly; any sanitizer report aborts (-fno-sanitize-recover).
 #define DSM_HOST_ONLY 1
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -368,6 +369,65 @@ static void fuzz_ogg() {
       Bytes pg = ogg_page(9, i, i == 0 ? 2 : 1, lacing, body);
       REQUIRE(dsm_ogg_demux_push(d, pg.data(), pg.size()) == 0);  // 2.6 MB of one never-ending packet: refused beyond 1 MiB
     }
+    dsm_ogg_demux_free(d);
+    ++n_cases;
+  }
+  {  // 4 MiB of fake page headers (version 0, 255 segments of 255 bytes) cost r02 a 65 307-byte CRC per candidate and
+     // ONE byte of progress — 2.4 s.  The resynchronisation budget bounds it: a fraction of a second even under ASan.
+    Bytes hostile;
+    Bytes fake = {'O', 'g', 'g', 'S', 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 0, 0, 0, 1, 0, 0, 0, 0xde, 0xad, 0xbe, 0xef, 255};
+    fake.insert(fake.end(), 255, 255);
+    while (hostile.size() < ((size_t)4 << 20)) hostile.insert(hostile.end(), fake.begin(), fake.end());
+    dsm_ogg_demux* d = dsm_ogg_demux_new();
+    const auto t0 = std::chrono::steady_clock::now();
+    REQUIRE(dsm_ogg_demux_push(d, hostile.data(), hostile.size()) == 0);
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    REQUIRE(secs < 1.5);  // measured: 0.05 s plain, 0.3 s under ASan + UBSan at -O1
+    // ... and the demultiplexer still locks on to a real stream behind it — once the last fake header's claimed 65 307
+    // bytes have arrived (any Ogg parser has to wait for a whole page before it can reject it)
+    Bytes head = {'O', 'p', 'u', 's', 'H', 'e', 'a', 'd', 1, 1, 0, 0, 0x80, 0xbb, 0, 0, 0, 0, 0};
+    Bytes pg = ogg_page(3, 0, 2, {(uint8_t)head.size()}, head);
+    REQUIRE(dsm_ogg_demux_push(d, pg.data(), pg.size()) >= 0);
+    int waiting = 0;
+    for (uint32_t i = 1; i < 400; ++i) {
+      Bytes body(200, (uint8_t)i);
+      pg = ogg_page(3, i, 0, {200}, body);
+      waiting = dsm_ogg_demux_push(d, pg.data(), pg.size());
+      REQUIRE(waiting >= 0);
+    }
+    REQUIRE(waiting > 50);  // 400 x 227 bytes: everything behind the first 65 KiB came through
+    const double secs2 = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    REQUIRE(secs2 < 3.0);
+    dsm_ogg_demux_free(d);
+    ++n_cases;
+  }
+  {  // a long body in ONE push: 6000 packets (two minutes of 20 ms frames) — r02 silently dropped everything past 4096
+    Bytes stream;
+    uint32_t seq2 = 0;
+    Bytes head = {'O', 'p', 'u', 's', 'H', 'e', 'a', 'd', 1, 1, 0, 0, 0x80, 0xbb, 0, 0, 0, 0, 0};
+    Bytes tags = {'O', 'p', 'u', 's', 'T', 'a', 'g', 's', 0, 0, 0, 0, 0, 0, 0, 0};
+    Bytes pg = ogg_page(11, seq2++, 2, {(uint8_t)head.size()}, head);
+    stream.insert(stream.end(), pg.begin(), pg.end());
+    pg = ogg_page(11, seq2++, 0, {(uint8_t)tags.size()}, tags);
+    stream.insert(stream.end(), pg.begin(), pg.end());
+    const int npk = 6000;
+    for (int p0 = 0; p0 < npk; p0 += 50) {
+      std::vector<uint8_t> lacing;
+      Bytes body;
+      for (int i = 0; i < 50; ++i) { lacing.push_back(40); for (int j = 0; j < 40; ++j) body.push_back((uint8_t)(p0 + i)); }
+      pg = ogg_page(11, seq2++, 0, lacing, body);
+      stream.insert(stream.end(), pg.begin(), pg.end());
+    }
+    dsm_ogg_demux* d = dsm_ogg_demux_new();
+    REQUIRE(dsm_ogg_demux_push(d, stream.data(), stream.size()) > 0);
+    int got = 0, hdrs = 0;
+    const uint8_t* pkt; size_t len; int hdr;
+    while (dsm_ogg_demux_next(d, &pkt, &len, &hdr) == 1) {
+      if (hdr) { ++hdrs; continue; }
+      REQUIRE(len == 40 && pkt[0] == (uint8_t)got);  // in order, none missing
+      ++got;
+    }
+    REQUIRE(hdrs == 2 && got == npk);
     dsm_ogg_demux_free(d);
     ++n_cases;
   }

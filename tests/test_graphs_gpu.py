@@ -25,6 +25,7 @@ def _run_asr(dsm, cfg, B, lm, mimi, steps, masks, resets, pcm):
         log.append((codes.copy(), text.copy(), prs.copy(), hid.copy(), dec.copy(), eng.poll_msgs()))
     m = eng.metrics()
     eng.close()
+    assert m.capture_failures == 0, m.capture_error  # a capture that does not hold is never silent (dsm_metrics, r03)
     return log, (m.graph_launches, m.eager_bodies)
 
 
@@ -66,6 +67,7 @@ def test_graph_replay_equals_eager_tts(gpu, dsm, lib, monkeypatch):
         out = [tuple(x.copy() for x in eng.step(prev, allowed, mask)) for prev, allowed, mask in schedule(cfg, B, steps)]
         m = eng.metrics()
         eng.close()
+        assert m.capture_failures == 0, m.capture_error
         return out, m.graph_launches, m.eager_bodies
 
     monkeypatch.setenv("DSM_GRAPHS", "0")

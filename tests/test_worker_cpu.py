@@ -130,3 +130,72 @@ def test_staged_calls_equal_the_single_call(dsm, lib, orc, tiny_weights):
         for slot in slots:
             assert wa.recv(slot) == wb.recv(slot)
     wa.close(); wb.close()
+
+
+def test_ticketed_backend_whose_encode_fails_once(dsm, lib, orc, tiny_weights):
+    """an encode_async that fails must cost one frame, not the pipeline.  A scripted ticket backend (the oracle
+    behind a four-entry ring, like the engine's) refuses one call: the worker reports the backend's error for that pass, and
+    every later frame still goes through with its own ticket — against a second worker whose backend never fails and that
+    is simply not sent the lost frame."""
+    import ctypes as C
+    cfg = dsm.config_tiny()
+    B, FRAME = 2, 1920
+
+    def make(fail_at):
+        ora = orc.OracleAsr(cfg, B, *tiny_weights)
+        be, keep = worker_ref.oracle_backend(dsm, ora, cfg, B)
+        ring = {"codes": {}, "next": 0, "calls": 0, "in_flight": set()}
+
+        def encode_async(_s, pcm, mask, ticket):
+            ring["calls"] += 1
+            if ring["calls"] == fail_at:
+                return -4  # DSM_ERR_STATE: nothing taken from the ring
+            t = ring["next"]
+            assert t not in ring["in_flight"], "the worker ran ahead of the ring"
+            p = np.ctypeslib.as_array(pcm, shape=(B, FRAME)).copy()
+            m = np.ctypeslib.as_array(mask, shape=(B,)).copy()
+            ring["codes"][t] = np.where(m[:, None].astype(bool), ora.encode_step(p, m, side=0), 0).astype(np.uint32)
+            ring["in_flight"].add(t)
+            ring["next"] = (t + 1) % 4
+            ticket[0] = t
+            return 0
+
+        def step_ticket(_s, t, mask, text, prs):
+            assert t in ring["in_flight"], f"ticket {t} was never handed out"
+            ring["in_flight"].discard(t)
+            m = np.ctypeslib.as_array(mask, shape=(B,)).copy()
+            tt, p = ora.step_tokens(ring["codes"].pop(t), m)
+            np.ctypeslib.as_array(text, shape=(B,))[:] = tt
+            if cfg.extra_heads_num:
+                np.ctypeslib.as_array(prs, shape=(cfg.extra_heads_num, B))[:] = p
+            return 0
+
+        cbs = (dsm.BE_ENCODE_ASYNC(encode_async), dsm.BE_STEP_TICKET(step_ticket))
+        be.encode_async, be.step_ticket = cbs
+        return dsm.Worker(backend=be), (keep, cbs, ora), ring
+
+    wa, keep_a, ring_a = make(fail_at=4)
+    wb, keep_b, ring_b = make(fail_at=-1)
+    sa, sb = [wa.open() for _ in range(B)], [wb.open() for _ in range(B)]
+    assert sa == sb
+    rng = np.random.default_rng(11)
+    failed = 0
+    for it in range(12):
+        frames = [(0.1 * rng.standard_normal(FRAME)).astype(np.float32) for _ in range(B)]
+        for slot, f in zip(sa, frames):
+            wa.send(slot, dsm.encode_in_msg("Audio", pcm=f))
+        try:
+            produced = wa.step_encode()
+        except dsm.DsmError:
+            failed += 1
+            produced = None  # this frame is gone (the reference's encoder thread would have died with it: srv/utils.rs:376-384)
+        if produced is None:
+            continue
+        for slot, f in zip(sb, frames):
+            wb.send(slot, dsm.encode_in_msg("Audio", pcm=f))
+        assert wb.step_encode() == produced
+        assert wa.step_model() == wb.step_model()
+        for slot in sa:
+            assert wa.recv(slot) == wb.recv(slot)
+    assert failed == 1 and not ring_a["in_flight"] and not ring_b["in_flight"]
+    wa.close(); wb.close()

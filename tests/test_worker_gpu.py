@@ -98,4 +98,9 @@ def test_two_thread_run_ahead_pipeline_delivers_the_same_messages(gpu, dsm, lib,
         assert sum(m["type"] == "Step" for m in want[s]) >= frames
         assert got[s] == want[s], f"slot {s}: pipelined worker delivered different messages"
     assert stats["max_ahead"] >= 1
+    # both threads were inside the library while the encode / LM-group sequences were captured: the captures must have held
+    # (capture_failures == 0) and the graphs must have been replayed (a silent eager fallback passed unnoticed)
+    m = eb.metrics()
+    assert m.capture_failures == 0, m.capture_error
+    assert m.graph_launches > 0
     wb.close(); eb.close()
