@@ -248,7 +248,7 @@ struct dsm_engine {
   // capturing: per host thread (the encoder thread may capture while the model thread launches eagerly)
   static thread_local bool capturing;
   bool capture_failed = false;
-  GraphSlot g_enc[2], g_grp[kMaxGroups], g_dec, g_tts[2];
+  GraphSlot g_enc[2], g_grp[kMaxGroups], g_dec, g_ttsg[kMaxGroups][2];
   std::atomic<uint64_t> graph_launches{0}, eager_bodies{0}, capture_failures{0};
   std::string capture_error;  // what the first failed capture reported (err_mu)
   // a capture that did not produce a graph is never silent: counted, its first reason kept for dsm_metrics

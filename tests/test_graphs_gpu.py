@@ -70,6 +70,7 @@ def test_graph_replay_equals_eager_tts(gpu, dsm, lib, monkeypatch):
         assert m.capture_failures == 0, m.capture_error
         return out, m.graph_launches, m.eager_bodies
 
+    monkeypatch.setenv("DSM_TTS_GROUPS", "1")
     monkeypatch.setenv("DSM_GRAPHS", "0")
     eager, g0, e0 = run()
     monkeypatch.delenv("DSM_GRAPHS")
@@ -77,7 +78,12 @@ def test_graph_replay_equals_eager_tts(gpu, dsm, lib, monkeypatch):
     assert g0 == 0 and e0 == steps
     # two variants (with / without the depformer), two settling runs each, plus a re-settle when a split-K workspace still grew
     assert g1 >= steps // 2 and g1 + e1 == steps and e1 <= 7, (g1, e1)
+    # two stream groups of two slots (r03): each group has its own stream, split-K workspace and pair of graphs
+    monkeypatch.setenv("DSM_TTS_GROUPS", "2")
+    grouped, g2, e2 = run()
+    assert g2 + e2 == 2 * steps and g2 >= steps, (g2, e2)
     sched = list(schedule(cfg, B, steps))
-    for s, (a, b) in enumerate(zip(eager, graph)):
+    for s, (a, b, c) in enumerate(zip(eager, graph, grouped)):
         act = np.asarray(sched[s][2]).astype(bool)
         assert np.array_equal(a[0][act], b[0][act]) and np.array_equal(a[1][act], b[1][act]), f"TTS tokens differ at step {s}"
+        assert np.array_equal(a[0][act], c[0][act]) and np.array_equal(a[1][act], c[1][act]), f"TTS tokens of the two-group engine differ at step {s}"
