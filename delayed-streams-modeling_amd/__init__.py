@@ -58,7 +58,8 @@ class TtsConfig(C.Structure):
         ("acoustic_delay", C.c_int), ("text_pad_token", C.c_int), ("text_bos_token", C.c_int),
         ("text_eos_token", C.c_int), ("text_eop_token", C.c_int), ("text_start_token", C.c_int),
         ("text_audio_delay_in_tokens", C.c_int), ("max_consecutive_pads", C.c_int), ("max_steps", C.c_int),
-        ("kv_bf16", C.c_int)]
+        ("kv_bf16", C.c_int), ("cross_attention", C.c_int), ("ca_norm", C.c_int), ("ca_dim", C.c_int),
+        ("ca_max_len", C.c_int), ("cfg_rows", C.c_int)]
 
 
 TTS_UNGENERATED = 0xFFFFFFFF
@@ -130,6 +131,7 @@ ABI_SYMBOLS = [
     "dsm_mimi_encode_step_async", "dsm_asr_step_tokens_ticket", "dsm_worker_recv", "dsm_worker_buffered",
     "dsm_tts_config_v202501", "dsm_tts_create", "dsm_tts_destroy", "dsm_tts_last_error", "dsm_tts_step",
     "dsm_tts_audio_tokens", "dsm_tts_step_idx", "dsm_tts_reset_slot", "dsm_tts_debug_read", "dsm_tts_get_metrics", "dsm_tts_set_sampling",
+    "dsm_tts_set_ca_src",
 ]
 PROF_TAGS = ["attn_lm", "gemm_lm", "attn_mimi", "gemm_mimi", "rvq", "other"]
 
@@ -244,6 +246,7 @@ def load_library(path=None):
     lib.dsm_tts_debug_read.argtypes = [vp, C.c_char_p, fp, C.c_size_t]
     lib.dsm_tts_get_metrics.argtypes = [vp, C.POINTER(Metrics)]
     lib.dsm_tts_set_sampling.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_uint64]
+    lib.dsm_tts_set_ca_src.argtypes = [vp, C.c_int, fp, C.c_int, fp, C.c_int, C.c_double]
     for name in ("dsm_tts_create", "dsm_tts_step", "dsm_tts_audio_tokens", "dsm_tts_step_idx", "dsm_tts_reset_slot",
                  "dsm_tts_debug_read"):
         getattr(lib, name).restype = C.c_int
@@ -318,9 +321,10 @@ def config_tts_v202501():
     return cfg
 
 
-def config_tts_tiny(kv_bf16=1):
+def config_tts_tiny(kv_bf16=1, cross_attention=False, cfg_rows=False, ca_dim=0, ca_norm=0):
     """Small TTS configuration with every structural feature of the v202501 model: shared depformer with
-    fewer weight groups than slices, low-rank embeddings, acoustic and text-audio delays."""
+    fewer weight groups than slices, low-rank embeddings, acoustic and text-audio delays.  cross_attention / cfg_rows:
+    the branch the reference server runs (norm_cross + cross-attention in every main-LM layer, two batch rows per slot)."""
     cfg = TtsConfig()
     t = cfg.lm
     t.d_model, t.num_heads, t.num_layers, t.dim_feedforward = 128, 4, 2, 512
@@ -337,6 +341,9 @@ def config_tts_tiny(kv_bf16=1):
     cfg.text_eos_token, cfg.text_eop_token, cfg.text_start_token = 2, 0, 40
     cfg.text_audio_delay_in_tokens, cfg.max_consecutive_pads, cfg.max_steps = 3, 4, 64
     cfg.kv_bf16 = kv_bf16
+    if cross_attention:
+        cfg.cross_attention, cfg.ca_norm, cfg.ca_dim, cfg.ca_max_len = 1, ca_norm, ca_dim, 24
+        cfg.cfg_rows = 1 if cfg_rows else 0
     return cfg
 
 
@@ -796,3 +803,11 @@ class TtsEngine:
     def set_sampling(self, slot, top_k, temperature, seed):
         """Sampling::TopK{k, temperature} seeded with `seed` for the slot's text and audio processors (srv/tts.rs:401-415)."""
         self._check(self.lib.dsm_tts_set_sampling(self.h, slot, top_k, temperature, seed))
+
+    def set_ca_src(self, slot, ca_src, ca_src_uncond=None, cfg_alpha=0.0):
+        """State::new's ca_src / cfg_alpha for the slot (srv/tts.rs:426-441): ca_src [n][ca_dim] f32 or None;
+        ca_src_uncond: the second batch row of a classifier-free-guidance request."""
+        a = None if ca_src is None else np.ascontiguousarray(ca_src, dtype=np.float32)
+        u = None if ca_src_uncond is None else np.ascontiguousarray(ca_src_uncond, dtype=np.float32)
+        self._check(self.lib.dsm_tts_set_ca_src(self.h, slot, _ptr(a), 0 if a is None else a.shape[0], _ptr(u),
+                                                0 if u is None else u.shape[0], float(cfg_alpha)))

@@ -59,6 +59,9 @@ struct ConvGeom {
 struct TLayerW {
   Linear in_proj, out_proj, ff_in, ff_out;
   float *n1w = nullptr, *n1b = nullptr, *n2w = nullptr, *n2b = nullptr, *ls1 = nullptr, *ls2 = nullptr;
+  // cross attention (TTS main LM, core/transformer.rs:205-330,747-763): in_proj_q, in_proj_kv, out_proj, norm_cross
+  Linear ca_q, ca_kv, ca_out;
+  float *ncw = nullptr, *ncb = nullptr;
 };
 
 struct TransformerW {
@@ -67,6 +70,21 @@ struct TransformerW {
   std::vector<TLayerW> layers;
   float* inv_freq = nullptr;
   bool rope_pos_before = false;  // non-batched transformer semantics (TTS main LM)
+  bool has_ca = false;           // every layer carries norm_cross + cross_attention
+  int ca_norm_rms = 0;           // norm_cross: RmsNorm (eps 1e-8) instead of LayerNorm (eps 1e-5)
+};
+
+// Per-row cross-attention sources of a transformer_forward call: the projected keys / values of every batch row's ca_src
+// (compute_kv, core/transformer.rs:299-318) laid out like a ring cache, [rows][H][smax][hd] per layer, so that attn_kernel
+// serves them: `last` = source length - 1 plays start_pos (every one of the `len` rows is visible, no causal mask), `act`
+// = the row attends this step (it is active and has a source).  `att` [rows][d] holds the attention output; rows that never
+// attend keep the zeros they were created with, so their out_proj term is +0 (ca_src = None: the layer adds nothing, :753-760).
+struct CaState {
+  std::vector<void*> k, v;
+  uint32_t* last = nullptr;
+  uint8_t* act = nullptr;
+  float* att = nullptr;
+  int smax = 0;
 };
 
 struct TransformerState {  // per (side): ring caches + ScatteredCacheBuilder state

@@ -1358,9 +1358,11 @@ __device__ inline uint32_t block_sample_topk(const float* __restrict__ lg, int V
 // force_eop, i.e. consecutive_pads > max_consecutive_pads)
 __global__ void tts_text_token_kernel(const float* __restrict__ logits, int V, const int32_t* __restrict__ allowed,
                                       const uint8_t* __restrict__ force_eop, uint32_t pad, uint32_t eop,
-                                      uint32_t* __restrict__ text_token, uint32_t* __restrict__ last_tok, SampleArgs sa) {
+                                      uint32_t* __restrict__ text_token, uint32_t* __restrict__ last_tok, SampleArgs sa,
+                                      const uint8_t* __restrict__ active) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int b = blockIdx.x;
+  if (!active[b]) return;  // a paused slot takes no step: in particular its text_lp draws nothing (r03: it used to advance the slot's generator)
   const int32_t al = allowed[b];
   uint32_t tok;
   if (al >= 0) tok = (uint32_t)al;
@@ -1381,15 +1383,45 @@ __global__ void tts_text_token_kernel(const float* __restrict__ logits, int V, c
   }
 }
 
-// e[b] = table[last_tok[b]] (LowRankEmbeddings::forward with the low-rank product folded into the table at load)
+// e[row] = table[last_tok[row / rps]] (LowRankEmbeddings::forward with the low-rank product folded into the table at load);
+// rps batch rows per slot: both rows of a guided slot take the slot's token (core/lm.rs:702-709)
 __global__ void dep_gather_kernel(float* __restrict__ e, const float* __restrict__ table,
-                                  const uint32_t* __restrict__ last_tok, int vocab, int D) {
+                                  const uint32_t* __restrict__ last_tok, int vocab, int D, int rps) {
   const int b = blockIdx.x;
-  uint32_t t = last_tok[b];
+  uint32_t t = last_tok[b / rps];
   if (t >= (uint32_t)vocab) t = 0;
   const float4* src = reinterpret_cast<const float4*>(table + (long)t * D);
   float4* dst = reinterpret_cast<float4*>(e + (long)b * D);
   for (int j = threadIdx.x; j < D / 4; j += blockDim.x) dst[j] = src[j];
+}
+
+// Classifier-free guidance mix of a slot's two batch rows — core/tts_streaming.rs:166-172, core/lm.rs:718-721:
+//   ((l0 * a)? - (l1 * (a - 1.))?)?   with Tensor * f64 = affine(mul, 0.): v * (mul as f32) + 0f32 on the CPU backend.
+// out [B][V]; rows [B * 2][V]; slots without guidance copy row 0.  grid (ceil(V / 256), B).
+__global__ void cfg_mix_kernel(float* __restrict__ out, const float* __restrict__ rows, int V, const uint8_t* __restrict__ on,
+                               const float* __restrict__ fa, const float* __restrict__ fb) {
+  const int b = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= V) return;
+  const float l0 = rows[(long)(2 * b) * V + j];
+  float o = l0;
+  if (on[b]) {
+    const float l1 = rows[(long)(2 * b + 1) * V + j];
+    const float x = l0 * fa[b] + 0.0f, y = l1 * fb[b] + 0.0f;
+    o = x - y;
+  }
+  out[(long)b * V + j] = o;
+}
+
+// compute_kv(CaSrc::Tokens) of one batch row — core/transformer.rs:299-318: kv [n][2][H][hd] (the in_proj_kv product) ->
+// K, V [H][smax][hd] in the cache dtype (rounded like the ring cache's rows).  kc / vc point at the row's block.
+template <typename KVT>
+__global__ void ca_kv_scatter_kernel(const float* __restrict__ kv, KVT* __restrict__ kc, KVT* __restrict__ vc, int n, int d,
+                                     int hd, int smax) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)n * d) return;
+  const int j = (int)(i / d), c = (int)(i % d), h = c / hd, ii = c % hd;
+  store_kv(kc + ((long)h * smax + j) * hd + ii, kv[(long)j * 2 * d + c]);
+  store_kv(vc + ((long)h * smax + j) * hd + ii, kv[(long)j * 2 * d + d + c]);
 }
 
 // DepFormer::sample slice epilogue: lp.sample (ArgMax, or seeded top-k per slot), forced pre-delay pad for the NEXT

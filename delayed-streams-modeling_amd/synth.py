@@ -139,8 +139,9 @@ def lm_spec(cfg):
     return s
 
 
-def tts_spec(cfg):
-    """TTS checkpoint keys (core/lm.rs:501-590): main LM + shared depformer with per-group gating/linear_in."""
+def tts_spec(cfg, legacy_ca=False):
+    """TTS checkpoint keys (core/lm.rs:501-590): main LM + shared depformer with per-group gating/linear_in.
+    cfg.cross_attention adds every layer's norm_cross + cross_attention tensors (legacy_ca: the single in_proj_weight layout)."""
     s = Spec()
     t, dp = cfg.lm, cfg.depformer
     d, D, S, G, lr = t.d_model, dp.d_model, cfg.dep_num_slices, cfg.dep_weight_groups, cfg.dep_low_rank
@@ -148,6 +149,21 @@ def tts_spec(cfg):
     for i in range(cfg.audio_codebooks):
         s.add(f"emb.{i}.weight", (cfg.audio_vocab_size, d), "normal", 0.3)
     _transformer_spec(s, "transformer", t, gating_hidden(t))
+    if cfg.cross_attention:  # norm_cross + cross_attention per layer (core/transformer.rs:747-763, :205-290 "Case 2" keys)
+        kvd = cfg.ca_dim or d
+        for l in range(t.num_layers):
+            p = f"transformer.layers.{l}"
+            if cfg.ca_norm == 1:
+                s.add(f"{p}.norm_cross.alpha", (1, 1, d), "alpha")
+            else:
+                s.add(f"{p}.norm_cross.weight", (d,), "alpha")
+                s.add(f"{p}.norm_cross.bias", (d,), "normal", 0.02)
+            if legacy_ca and kvd == d:  # "Case 1": one in_proj_weight [d + 2d, d], rows q | k | v
+                s.add(f"{p}.cross_attention.in_proj_weight", (3 * d, d), "normal", d ** -0.5)
+            else:
+                s.add(f"{p}.cross_attention.in_proj_weight_q", (d, d), "normal", d ** -0.5)
+                s.add(f"{p}.cross_attention.in_proj_weight_kv", (2 * d, kvd), "normal", kvd ** -0.5)
+            s.add(f"{p}.cross_attention.out_proj.weight", (d, d), "normal", d ** -0.5)
     s.add("out_norm.alpha", (1, 1, d), "alpha")
     s.add("text_linear.weight", (cfg.text_out_vocab_size, d), "normal", d ** -0.5)
     for g in range(G):
@@ -175,12 +191,19 @@ def tts_spec(cfg):
     return s
 
 
-def make_synth_tts_weights(cfg, out_dir, seed=SEED, tag="tts"):
+def make_synth_tts_weights(cfg, out_dir, seed=SEED, tag="tts", legacy_ca=False):
+    """The tag must tell configurations apart (files are cached by name): use e.g. "tts_tiny_ca" with cfg.cross_attention."""
     os.makedirs(out_dir, exist_ok=True)
     path = os.path.join(out_dir, f"{tag}.lm.safetensors")
     if not os.path.exists(path):
-        write_safetensors(path, tts_spec(cfg), "BF16", seed)
+        write_safetensors(path, tts_spec(cfg, legacy_ca), "BF16", seed)
     return path
+
+
+def synth_ca_src(cfg, n, seed):
+    """A cross-attention source [n][ca_dim] f32 (the voice's `ca_src` tensor of srv/tts.rs:340-347: speaker-encoder output)."""
+    rng = np.random.default_rng(seed)
+    return rng.standard_normal((n, cfg.ca_dim or cfg.lm.d_model)).astype(np.float32)
 
 
 def _conv(s, prefix, out_c, in_c, k, bias=True):

@@ -277,6 +277,16 @@ typedef struct dsm_tts_config {
   int acoustic_delay, text_pad_token, text_bos_token, text_eos_token, text_eop_token, text_start_token;
   int text_audio_delay_in_tokens, max_consecutive_pads, max_steps;
   int kv_bf16;
+  /* The branch the reference's TTS server runs (srv/tts.rs:426-441: State::new(.., Some(CaSrc::Tokens(ca_src)), .., cfg_alpha, ..)):
+   * cross-attention to a speaker-conditioning source in every main-LM layer (core/lm.rs:392-396 tts_202501:
+   * cross_attention = Some((Normal, LayerNorm, None)); core/transformer.rs:205-330,747-763) and classifier-free guidance
+   * (core/tts_streaming.rs:164-173,207-214).  All zero = the `ca_src = None`, `cfg_alpha = None` path. */
+  int cross_attention;   /* 1: every main-LM layer carries norm_cross + cross_attention.{in_proj_weight_q, in_proj_weight_kv, out_proj}
+                            (or the legacy single in_proj_weight); gating must be CrossAttentionGating::Normal */
+  int ca_norm;           /* norm_cross: 0 LayerNorm (eps 1e-5, weight|alpha + bias), 1 RmsNorm (eps 1e-8, alpha) — cfg.cross_attention.1 */
+  int ca_dim;            /* width of a cross-attention source row (kv_in_dim, cfg.cross_attention.2); 0 = d_model */
+  int ca_max_len;        /* longest source (rows of ca_src) a slot may be given with dsm_tts_set_ca_src */
+  int cfg_rows;          /* 1: every slot owns TWO batch rows (conditional, unconditional) so that it can run with a cfg_alpha */
 } dsm_tts_config;
 void dsm_tts_config_v202501(dsm_tts_config* out); /* Config::v202501 + configs/tts/config-tts.toml with a consistent depformer */
 
@@ -300,7 +310,18 @@ int dsm_tts_reset_slot(dsm_tts*, int slot);
  * reference's order among the k survivors is an implementation detail of Rust's select_nth_unstable_by and no vector of
  * candle's / rand's exists offline: sampled tokens are pinned engine-vs-oracle only ("parity unpinned" vs Candle). */
 int dsm_tts_set_sampling(dsm_tts*, int slot, int top_k, float temperature, uint64_t seed);
-int dsm_tts_debug_read(dsm_tts*, const char* name, float* out, size_t cap); /* "lm.hidden", "lm.logits" */
+/* The slot's cross-attention source and guidance — the `ca_src` / `cfg_alpha` arguments of tts_streaming::State::new
+ * (core/tts_streaming.rs:70-100; built at srv/tts.rs:426-441 from the voice's `ca_src` tensor, with the speaker encoder's
+ * empty conditioning appended as a second batch row when the query carries a cfg_alpha).
+ *   ca_src [n][ca_dim] f32, host: CaSrc::Tokens of batch row 0.  Its keys and values (in_proj_kv, core/transformer.rs:299-318)
+ *     are projected ONCE here into a per-slot device buffer; the reference recomputes the same values every step.
+ *     NULL / n = 0: ca_src = None (cross-attention is skipped for the slot: core/transformer.rs:753-760).
+ *   ca_src_uncond [n_uncond][ca_dim] or NULL: batch row 1 (needs cfg_rows = 1).  With it the slot runs both rows and mixes
+ *     text logits and every depformer slice's logits as l0 * a - l1 * (a - 1), a = cfg_alpha (core/tts_streaming.rs:166-172,
+ *     core/lm.rs:718-721: Tensor * f64 = affine(mul as f32, 0)), sampling once per slot.
+ * Needs cfg.cross_attention; n, n_uncond <= ca_max_len.  dsm_tts_reset_slot clears both (a fresh State). */
+int dsm_tts_set_ca_src(dsm_tts*, int slot, const float* ca_src, int n, const float* ca_src_uncond, int n_uncond, double cfg_alpha);
+int dsm_tts_debug_read(dsm_tts*, const char* name, float* out, size_t cap); /* "lm.hidden", "lm.logits": one row per BATCH ROW (2 per slot with cfg_rows) */
 int dsm_tts_get_metrics(dsm_tts*, dsm_metrics* out); /* graph_launches / eager_bodies only */
 
 /* The LM step splits the batch into stream groups (slots [first, first+n) each on its own HIP stream) so that one

@@ -1058,6 +1058,10 @@ typedef struct {
   float *ff_in, *ff_out;           /* gating: linear_in [2*hid][d], linear_out [d][hid]; else linear1 [ff][d], linear2 [d][ff] */
   float *ls1, *ls2;                /* layer scales or NULL */
   float *k_cache, *v_cache;        /* [B][H][ctx][hd] — ScatteredKvCache, core/kv_cache.rs:21-25 */
+  /* cross attention — core/transformer.rs:205-330 (StreamingMultiheadCrossAttention), :747-763 (norm_cross) */
+  float *ca_q, *ca_kv, *ca_out;    /* in_proj_q [d][d], in_proj_kv [2d][kvd], out_proj [d][d]; NULL without cross attention */
+  float *nc_w, *nc_b;              /* norm_cross */
+  float *ca_k, *ca_v;              /* [B][H][ca_max][hd]: compute_kv(CaSrc::Tokens) of every row's source (:299-318) */
 } orc_tlayer;
 
 typedef struct {
@@ -1068,6 +1072,8 @@ typedef struct {
   orc_tlayer* layers;
   orc_kvb* builder;
   float* inv_freq;
+  int has_ca, ca_norm_rms, ca_dim, ca_max; /* cross attention: norm_cross type, source row width, rows reserved per batch row */
+  int* ca_len;                             /* [B] rows of the batch row's source; 0 = ca_src None (the layer skips it, :753-760) */
 } orc_transformer;
 
 static int gating_hidden(const dsm_transformer_config* c) { /* core/batched_transformer.rs:153-157 */
@@ -1125,11 +1131,76 @@ static void transformer_free(orc_transformer* t) {
     orc_tlayer* L = &t->layers[l];
     free(L->in_proj); free(L->out_proj); free(L->norm1_w); free(L->norm1_b); free(L->norm2_w); free(L->norm2_b);
     free(L->ff_in); free(L->ff_out); free(L->ls1); free(L->ls2); free(L->k_cache); free(L->v_cache);
+    free(L->ca_q); free(L->ca_kv); free(L->ca_out); free(L->nc_w); free(L->nc_b); free(L->ca_k); free(L->ca_v);
   }
   free(t->layers);
   orc_kvb_free(t->builder);
   free(t->inv_freq);
+  free(t->ca_len);
   free(t);
+}
+
+/* StreamingMultiheadCrossAttention::new — core/transformer.rs:219-290: "Case 1" a single in_proj_weight [d + 2d][d]
+ * (rows q | kv), "Case 2" in_proj_weight_q [d][d] + in_proj_weight_kv [2d][kv_in_dim]; out_proj; gating = Normal.
+ * norm_cross — :735-738 (Norm::new_shortcut with cfg.cross_attention.1). */
+static void transformer_load_cross_attention(orc_transformer* t, wsrc* s, const char* prefix, int ca_norm_rms, int ca_dim,
+                                             int ca_max) {
+  const int d = t->cfg.d_model, H = t->cfg.num_heads, hd = d / H;
+  t->has_ca = 1;
+  t->ca_norm_rms = ca_norm_rms;
+  t->ca_dim = ca_dim > 0 ? ca_dim : d;
+  t->ca_max = ca_max;
+  t->ca_len = (int*)xcalloc((size_t)t->B, sizeof(int));
+  for (int l = 0; l < t->cfg.num_layers; ++l) {
+    orc_tlayer* L = &t->layers[l];
+    if (w_has(s, "%s.layers.%d.cross_attention.in_proj_weight", prefix, l)) {
+      float* w = w_get(s, (int64_t)3 * d * d, "%s.layers.%d.cross_attention.in_proj_weight", prefix, l);
+      L->ca_q = (float*)xmalloc(sizeof(float) * (size_t)d * d);
+      L->ca_kv = (float*)xmalloc(sizeof(float) * (size_t)2 * d * d);
+      if (w) {
+        memcpy(L->ca_q, w, sizeof(float) * (size_t)d * d);                      /* narrow(0, 0, embed_dim) */
+        memcpy(L->ca_kv, w + (size_t)d * d, sizeof(float) * (size_t)2 * d * d); /* narrow(0, embed_dim, 2 * out_kv_dim) */
+      }
+      free(w);
+    } else {
+      L->ca_q = w_get(s, (int64_t)d * d, "%s.layers.%d.cross_attention.in_proj_weight_q", prefix, l);
+      L->ca_kv = w_get(s, (int64_t)2 * d * t->ca_dim, "%s.layers.%d.cross_attention.in_proj_weight_kv", prefix, l);
+    }
+    L->ca_out = w_get(s, (int64_t)d * d, "%s.layers.%d.cross_attention.out_proj.weight", prefix, l);
+    if (ca_norm_rms) {
+      L->nc_w = w_get(s, d, "%s.layers.%d.norm_cross.alpha", prefix, l);
+    } else {
+      L->nc_b = w_get(s, d, "%s.layers.%d.norm_cross.bias", prefix, l);
+      if (w_has(s, "%s.layers.%d.norm_cross.alpha", prefix, l))
+        L->nc_w = w_get(s, d, "%s.layers.%d.norm_cross.alpha", prefix, l);
+      else
+        L->nc_w = w_get(s, d, "%s.layers.%d.norm_cross.weight", prefix, l);
+    }
+    L->ca_k = (float*)xcalloc((size_t)t->B * H * ca_max * hd, sizeof(float));
+    L->ca_v = (float*)xcalloc((size_t)t->B * H * ca_max * hd, sizeof(float));
+  }
+}
+
+/* compute_kv(CaSrc::Tokens(xs)) for one batch row — core/transformer.rs:299-318: kv = in_proj_kv(xs) reshaped
+ * (t, 2, H, hd); k = kv[:, 0], v = kv[:, 1], kept as [H][t][hd].  Stored in the cache dtype like the ring (kv_bf16). */
+static void transformer_set_ca_src(orc_transformer* t, int row, const float* src, int n) {
+  const int d = t->cfg.d_model, H = t->cfg.num_heads, hd = d / H;
+  t->ca_len[row] = n;
+  if (n == 0) return;
+  float* kv = (float*)xmalloc(sizeof(float) * (size_t)n * 2 * d);
+  for (int l = 0; l < t->cfg.num_layers; ++l) {
+    orc_tlayer* L = &t->layers[l];
+    orc_linear(kv, 2 * d, src, t->ca_dim, L->ca_kv, t->ca_dim, NULL, n, 2 * d, t->ca_dim);
+    for (int j = 0; j < n; ++j)
+      for (int h = 0; h < H; ++h)
+        for (int i = 0; i < hd; ++i) {
+          const float kk = kv[(size_t)j * 2 * d + (size_t)h * hd + i], vv = kv[(size_t)j * 2 * d + d + (size_t)h * hd + i];
+          const size_t at = (((size_t)row * H + h) * t->ca_max + j) * hd + i;
+          L->ca_k[at] = t->kv_bf16 ? dsm_bf16_to_f32(dsm_f32_to_bf16(kk)) : kk;
+          L->ca_v[at] = t->kv_bf16 ? dsm_bf16_to_f32(dsm_f32_to_bf16(vv)) : vv;
+        }
+  }
+  free(kv);
 }
 
 static void norm_apply(const orc_transformer* t, float* y, const float* x, const float* w, const float* b, int rows) {
@@ -1205,6 +1276,28 @@ static void transformer_forward(orc_transformer* tr, float* xs, int T, const uin
         if (L->ls1) v = v * L->ls1[j]; /* LayerScale — core/transformer.rs:97-101 */
         xs[i * d + j] = xs[i * d + j] + v;
       }
+    if (tr->has_ca) { /* core/transformer.rs:753-760: xs = xs + cross_attn(norm_cross(xs), ca_src) for rows that have a source */
+      if (tr->ca_norm_rms) orc_rmsnorm(nrm, xs, L->nc_w, B * T, d, 1e-8f);
+      else orc_layernorm(nrm, xs, L->nc_w, L->nc_b, B * T, d, 1e-5f);
+      orc_linear(qkv, d, nrm, d, L->ca_q, d, NULL, B * T, d, d); /* in_proj_q; (b, t, H, hd) — :326-329 */
+      float* zmask = (float*)xcalloc((size_t)(tr->ca_max > 0 ? tr->ca_max : 1), sizeof(float)); /* mask = None */
+      memset(att, 0, sizeof(float) * (size_t)B * T * d);
+#pragma omp parallel for schedule(dynamic) collapse(2)
+      for (int b = 0; b < B; ++b)
+        for (int h = 0; h < H; ++h) {
+          const int n = tr->ca_len[b];
+          if (n == 0 || (mask && !mask[b])) continue;
+          for (int t = 0; t < T; ++t) /* softmax(q k^T hd^-1/2) v over the n source rows — :333-345, same canonical order as self attention */
+            orc_attention_head(qkv + ((size_t)b * T + t) * d + (size_t)h * hd, 1, L->ca_k + ((size_t)b * H + h) * tr->ca_max * hd,
+                               L->ca_v + ((size_t)b * H + h) * tr->ca_max * hd, n, hd, zmask, att + ((size_t)b * T + t) * d + (size_t)h * hd);
+        }
+      free(zmask);
+      orc_linear(prj, d, att, d, L->ca_out, d, NULL, B * T, d, d); /* out_proj, gating = Normal (identity) — :346-351 */
+      for (int b = 0; b < B; ++b) {
+        if (tr->ca_len[b] == 0) continue; /* (Some(cross_attn), None) => xs */
+        for (size_t i = (size_t)b * T * d; i < (size_t)(b + 1) * T * d; ++i) xs[i] = xs[i] + prj[i];
+      }
+    }
     norm_apply(tr, nrm, xs, L->norm2_w, L->norm2_b, B * T);
     /* Mlp::forward — :166-179 */
     if (c->gating) {

@@ -114,6 +114,7 @@ int orc_tts_audio_tokens(orc_tts*, int slot, int step, uint32_t* out);
 int orc_tts_step_idx(orc_tts*, int slot);
 int orc_tts_reset_slot(orc_tts*, int slot);
 int orc_tts_set_sampling(orc_tts*, int slot, int top_k, float temperature, uint64_t seed);
+int orc_tts_set_ca_src(orc_tts*, int slot, const float* ca_src, int n, const float* ca_src_uncond, int n_uncond, double cfg_alpha);
 uint32_t orc_sample_topk(const float* logits, int V, int k, float inv_t, const uint32_t* key, uint32_t* pos);
 uint32_t orc_chacha_word(const uint32_t* key, uint64_t index, int rounds);
 void orc_seed_from_u64(uint64_t seed, uint32_t* key);

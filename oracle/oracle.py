@@ -93,6 +93,7 @@ def lib():
         L.orc_tts_reset_slot.argtypes = [vp, C.c_int]
         L.orc_tts_debug_read.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
         L.orc_tts_set_sampling.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_uint64]
+        L.orc_tts_set_ca_src.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_double]
         L.orc_sample_topk.argtypes = [vp, C.c_int, C.c_int, C.c_float, vp, vp]
         L.orc_sample_topk.restype = C.c_uint32
         L.orc_chacha_word.argtypes = [vp, C.c_uint64, C.c_int]
@@ -254,6 +255,14 @@ class OracleTts:
 
     def set_sampling(self, slot, top_k, temperature, seed):
         self.L.orc_tts_set_sampling(self.h, slot, top_k, temperature, seed)
+
+    def set_ca_src(self, slot, ca_src, ca_src_uncond=None, cfg_alpha=0.0):
+        a = None if ca_src is None else np.ascontiguousarray(ca_src, dtype=np.float32)
+        u = None if ca_src_uncond is None else np.ascontiguousarray(ca_src_uncond, dtype=np.float32)
+        rc = self.L.orc_tts_set_ca_src(self.h, slot, None if a is None else p(a), 0 if a is None else a.shape[0],
+                                       None if u is None else p(u), 0 if u is None else u.shape[0], float(cfg_alpha))
+        if rc < 0:
+            raise RuntimeError(f"oracle set_ca_src failed ({rc})")
 
     def debug_read(self, name, n):
         out = np.zeros(n, dtype=np.float32)
