@@ -18,6 +18,7 @@ per-step collective; the shared weights are fanned out once at load with an RCCL
 import argparse
 import ctypes as C
 import json
+import subprocess
 import os
 import sys
 import time
@@ -35,6 +36,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64, help="stream slots per GPU")
     ap.add_argument("--config", default="stt-1b-en_fr", choices=["stt-1b-en_fr", "stt-2.6b-en", "tiny"])
+    ap.add_argument("--host-path-legs", default="400,2048",
+                    help="batch sizes for the end-to-end host-path legs (tools/host_path_bench: msgpack in, worker threads, H2D, "
+                         "msgpack out); empty = skip")
+    ap.add_argument("--host-path-frames", type=int, default=16)
     ap.add_argument("--workload", default="stt", choices=["stt", "mimi-decode", "tts"],
                     help="stt = Mimi encode + LM decode (the headline metric); mimi-decode = Mimi::decode_step only (config 5)")
     ap.add_argument("--no-fill", action="store_true", help="skip the untimed ring-cache fill (debug only)")
@@ -378,6 +383,24 @@ def main():
                 legs[Bl] = {"error": str(ex)[:200]}
             torch.cuda.empty_cache()
 
+    # ---- host-path legs (N = 1 only): the same batches driven end to end from HOST audio through the worker — per-channel
+    # msgpack InMsg::Audio decode, the reference's encoder / model thread split with run-ahead, pinned staging + H2D, LM step,
+    # OutMsg::Step fan-out and drain (tools/host_path_bench.cpp).  VERDICT r02 #5: the device-resident legs above say nothing
+    # about the host side at 2 048 slots. ----
+    host_legs = {}
+    if world == 1 and args.host_path_legs and args.config == "stt-1b-en_fr" and args.part == "all" and not args.no_overlap:
+        exe = os.path.join(ROOT, "tools", "host_path_bench")
+        for Bl in [int(x) for x in args.host_path_legs.split(",") if x]:
+            try:
+                if not os.path.exists(exe):
+                    raise RuntimeError("tools/host_path_bench is not built (__graft_entry__.build())")
+                r = subprocess.run([exe, lm_path, mimi_path, str(Bl), str(args.host_path_frames), "8"], capture_output=True, text=True, timeout=240)
+                if r.returncode != 0:
+                    raise RuntimeError((r.stderr or r.stdout)[-200:])
+                host_legs[Bl] = json.loads(r.stdout.strip().splitlines()[-1])
+            except Exception as ex:
+                host_legs[Bl] = {"error": str(ex)[:200]}
+
     if rank == 0:
         H, hd, L = cfg.lm.num_heads, cfg.lm.d_model // cfg.lm.num_heads, cfg.lm.num_layers
         kv_b = 2 if cfg.kv_bf16 else 4
@@ -460,6 +483,20 @@ def main():
                                "rtf_b400": legs.get(400, {}).get("rtf"),
                                "note": "same engine build and weight arena, ring positions jumped to steady state, two-stream pipeline, "
                                        "timed without instrumentation; north star: >= 400 real-time streams per MI355X"}
+            if host_legs:
+                # what can be promised: the largest measured batch whose RTF keeps a 10 % margin on BOTH the device-resident step
+                # and (where it was driven) the whole host path
+                def rtf_of(b):
+                    r = legs[b].get("rtf", 0.0)
+                    h = host_legs.get(b, {}).get("rtf")
+                    return min(r, h) if h is not None else r
+                safe = [b for b in legs if "rtf" in legs[b] and rtf_of(b) >= 1.10]
+                out["capacity"]["host_path"] = {
+                    "legs": {str(b): v for b, v in host_legs.items()},
+                    "what": "end to end from host audio: msgpack InMsg::Audio per channel (8 feeder threads) -> dsm_worker_send -> "
+                            "dsm_worker_step_encode (pre_process, pinned staging, H2D, Mimi encode; run-ahead) || dsm_worker_step_model "
+                            "(LM step, post_process, OutMsg::Step per channel) -> dsm_worker_recv; free-running, rtf = 80 ms / ms_per_frame",
+                    "streams_at_rtf_ge_1p10_device_and_host": max(safe) if safe else None}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, B, lm_path, mimi_path, args.cpu_steps)
         print(json.dumps(out))
