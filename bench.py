@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64, help="stream slots per GPU")
     ap.add_argument("--config", default="stt-1b-en_fr", choices=["stt-1b-en_fr", "stt-2.6b-en", "tiny"])
+    ap.add_argument("--spawn-check-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)      # tests: this rank raises mid-run
+    ap.add_argument("--spawn-check-arena-skew-rank", type=int, default=-1, help=argparse.SUPPRESS)  # tests: this rank reports another arena size
     ap.add_argument("--host-path-legs", default="400,2048",
                     help="batch sizes for the end-to-end host-path legs (tools/host_path_bench: msgpack in, worker threads, H2D, "
                          "msgpack out); empty = skip")
@@ -183,6 +185,20 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+def rank_report(dist, torch, dev, ms_per_step, arena_bytes):
+    """Every rank's step time and arena size on every rank (all_gather): rank 0 prints them, and ANY rank that sees a
+    disagreement about the weight arena exits non-zero (a rank that attached to different bytes would serve different
+    weights: SURVEY.md §8(e))."""
+    mine = torch.tensor([ms_per_step, float(arena_bytes)], dtype=torch.float64, device=dev)
+    allr = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(allr, mine)
+    per_rank_ms = [float(t[0].item()) for t in allr]
+    arenas = [int(t[1].item()) for t in allr]
+    if len(set(arenas)) != 1:
+        raise SystemExit("ranks disagree about the weight arena: %s bytes" % arenas)
+    return per_rank_ms
+
+
 def spawn_check(args, world, rank):
     """CPU rehearsal of the N > 1 control path (tests/test_bench_spawn_cpu.py): gloo process group, the load-time
     broadcast of a byte blob, barrier-bracketed timing with a MAX over ranks, one JSON line on rank 0.  No engine."""
@@ -197,14 +213,20 @@ def spawn_check(args, world, rank):
     dist.barrier()
     t0 = time.perf_counter()
     time.sleep(0.01 * (rank + 1))
+    if rank == args.spawn_check_fail_rank:
+        # a rank dying mid-run: the launcher (torch.distributed.run's agent) must take the others down from their barrier and
+        # hand a non-zero exit code to `bench.py --gpus N` — no hang, no JSON line that looks like a result
+        raise RuntimeError("spawn-check: rank %d fails on purpose" % rank)
     dist.barrier()
-    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    own = time.perf_counter() - t0
+    dt = torch.tensor([own], dtype=torch.float64)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     flags = torch.tensor([1 if ok else 0], dtype=torch.int64)
     dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+    per_rank = rank_report(dist, torch, torch.device("cpu"), own * 1000.0, (1 << 16) + (1 if rank == args.spawn_check_arena_skew_rank else 0))
     if rank == 0:
         print(json.dumps({"metric": "spawn-check", "n_gpus": world, "value": float(dt.item()), "unit": "s", "steps": args.steps,
-                          "warmup": args.warmup, "broadcast_ok": bool(flags.item()), "backend": "gloo"}))
+                          "warmup": args.warmup, "broadcast_ok": bool(flags.item()), "backend": "gloo", "per_rank_ms": per_rank}))
     dist.destroy_process_group()
 
 
@@ -337,8 +359,10 @@ def main():
     dt_t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
+    own_ms = dt / args.steps * 1000.0
     dt = float(dt_t.item())
     ms_per_step = dt / args.steps * 1000.0
+    per_rank_ms = rank_report(dist, torch, dev, own_ms, eng.weight_arena()[1]) if world > 1 else [own_ms]
 
     # ---- separate pass (not part of `value`): the dominant kernel bracketed live, i.e. with the other streams running
     # beside it — HIP events on the stream it is launched on + the in-kernel device-clock bracket ----
@@ -460,6 +484,8 @@ def main():
                        "rccl_ranks": world if world > 1 else None,
                        "weights_broadcast_ms": fan["broadcast_ms"] if fan else None,
                        "weights_broadcast_bytes": fan["arena_bytes"] if fan else None,
+                       "weights_broadcast_gbps": (fan["arena_bytes"] / (fan["broadcast_ms"] * 1e-3) / 1e9) if fan and fan["broadcast_ms"] > 0 else None,
+                       "per_rank_ms_per_step": per_rank_ms,
                        "weights_broadcast": "packed device weight arena, rank 0 -> all, RCCL over xGMI, once at load" if fan else None,
                        "timed_region": "instrumentation off; roofline brackets come from a separate %d-step pass (%.3f ms/step with the brackets on)"
                                        % (n_prof, dt_prof / n_prof * 1000.0)},

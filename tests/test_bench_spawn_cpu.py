@@ -22,6 +22,34 @@ def test_gpus_flag_spawns_that_many_ranks():
     assert out["value"] >= 0.02  # MAX over ranks: rank 1 slept 20 ms
 
 
+def _spawn(extra, timeout=300):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "2"
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--spawn-check", "--steps", "3", "--warmup", "1"] + extra,
+                          capture_output=True, text=True, timeout=timeout, env=env)
+
+
+def test_a_rank_that_dies_mid_run_fails_the_whole_bench_instead_of_hanging():
+    """rank 1 raises between the two barriers of the timed region; rank 0 is parked in the second one.  The
+    launcher has to take it down and `bench.py --gpus 2` has to return non-zero, without a JSON line, well inside the timeout."""
+    r = _spawn(["--spawn-check-fail-rank", "1"], timeout=240)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], r.stdout
+
+
+def test_ranks_that_disagree_about_the_weight_arena_fail_the_bench():
+    r = _spawn(["--spawn-check-arena-skew-rank", "1"], timeout=240)
+    assert r.returncode != 0
+    assert "disagree about the weight arena" in r.stdout + r.stderr
+
+
+def test_rank0_line_carries_every_ranks_time():
+    r = _spawn([])
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert len(out["per_rank_ms"]) == 2 and out["per_rank_ms"][1] >= out["per_rank_ms"][0] * 0.5
+
+
 def test_parent_does_not_import_torch_before_spawning():
     """The spawning parent must not initialise anything GPU-related: it may not even import torch."""
     src = open(os.path.join(ROOT, "bench.py")).read()
