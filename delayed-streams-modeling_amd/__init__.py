@@ -41,7 +41,7 @@ class AsrConfig(C.Structure):
         ("lm", TransformerConfig), ("text_in_vocab_size", C.c_int), ("text_out_vocab_size", C.c_int),
         ("audio_vocab_size", C.c_int), ("audio_codebooks", C.c_int), ("extra_heads_num", C.c_int),
         ("extra_heads_dim", C.c_int), ("asr_delay_in_tokens", C.c_int), ("temperature", C.c_float),
-        ("mimi", MimiConfig), ("kv_bf16", C.c_int)]
+        ("mimi", MimiConfig), ("kv_bf16", C.c_int), ("dot_mode", C.c_int)]
 
     def copy(self):
         out = AsrConfig()
@@ -59,7 +59,7 @@ class TtsConfig(C.Structure):
         ("text_eos_token", C.c_int), ("text_eop_token", C.c_int), ("text_start_token", C.c_int),
         ("text_audio_delay_in_tokens", C.c_int), ("max_consecutive_pads", C.c_int), ("max_steps", C.c_int),
         ("kv_bf16", C.c_int), ("cross_attention", C.c_int), ("ca_norm", C.c_int), ("ca_dim", C.c_int),
-        ("ca_max_len", C.c_int), ("cfg_rows", C.c_int)]
+        ("ca_max_len", C.c_int), ("cfg_rows", C.c_int), ("dot_mode", C.c_int)]
 
 
 TTS_UNGENERATED = 0xFFFFFFFF

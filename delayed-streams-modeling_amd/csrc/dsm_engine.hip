@@ -213,6 +213,7 @@ struct dsm_engine {
   bool gate_occ3 = false;     // DSM_GATE_OCC3=1: the gate's whole-K kernel squeezed to 168 VGPRs (three waves per SIMD, 80 B of spills)
   int loop_depth = 4;         // DSM_LOOP_DEPTH=2: two-block rolling window (fewer registers, three waves per SIMD) where four is the default
   size_t attn_lds_pad = 60000;  // DSM_ATTN_LDS_PAD: extra dynamic LDS per attention workgroup of a large launch (2 per CU)
+  int dot_mode = 0;           // dsm_asr_config.dot_mode / dsm_tts_config.dot_mode: 1 = the bf16-weight GEMMs in "bx3" (gemm_bx3_kernel)
   int attn_nt = 1;            // DSM_ATTN_NT: ring-cache rows with non-temporal loads: 0 never, 1 bf16 rings (default), 2 every ring
   bool fuse_front = true;     // DSM_FUSE_FRONT=0: the SEANet front end as three GEMM launches (r01)
   int smallk_loop = 1;        // DSM_SMALLK_LOOP=0: one-chunk GEMMs (K <= 256) over many m-tiles stay on gemm_tile_kernel (r01)
@@ -921,7 +922,8 @@ int launch_gemm_tiled(dsm_engine* e, hipStream_t st, GemmArgs& a) {
   // workgroup is one short dependent chain — loads, one to six MFMA blocks, residual load, store — so what counts is how
   // many of them a CU holds; gemm_tile_kernel's up-front window of eight blocks costs 200-230 VGPRs (two workgroups per CU),
   // gemm_loop_kernel's two-block window 150 (three).  Mimi encode alone at B = 2048: 17.7 -> 16.6 ms; 8-row tiles no better.
-  const bool smallk = e->smallk_loop && chunks == 1 && a.chunk_loop == 0 && (long)gx * ((a.M + 63) / 64) >= e->smallk_min_tiles;
+  const bool smallk = e->smallk_loop && chunks == 1 && a.chunk_loop == 0 && (long)gx * ((a.M + 63) / 64) >= e->smallk_min_tiles &&
+                      !(e->dot_mode == 1 && sizeof(WT) == 2);
   if (smallk && e->smallk_mt < MT) MT = e->smallk_mt;
   auto ok4 = [](const RowMap& m) { return m.ld % 4 == 0 && m.bstride % 4 == 0; };
   a.vec = (a.N % 4 == 0) && (!a.Y || ok4(a.ymap)) && (!a.Y2 || ok4(a.y2map)) && (!a.res || ok4(a.rmap));
@@ -951,6 +953,7 @@ int launch_gemm_tiled(dsm_engine* e, hipStream_t st, GemmArgs& a) {
   dim3 grid(gx, chunks, (a.M + 16 * MT - 1) / (16 * MT));
   a.ts = e->timeline ? e->dev_ts_slot(e->tag_gemm[e->sid(st)], e->sid(st), 1, 2) : nullptr;
   const int ph = e->prof_begin(e->tag_gemm[e->sid(st)], st);
+  const bool bx3 = e->dot_mode == 1 && sizeof(WT) == 2;  // dot_mode 1: every bf16-weight GEMM on the bf16 matrix pipe
   const bool roll = (a.chunk_loop > 1 && e->roll_prefetch) || smallk;  // whole K in the workgroup with a rolling load window
   constexpr int DMAX = LoopDepth<WT, NT>::MAX;
   const bool deep = DMAX == 4 && e->loop_depth == 4 && !smallk;
@@ -963,7 +966,13 @@ int launch_gemm_tiled(dsm_engine* e, hipStream_t st, GemmArgs& a) {
   else if (roll && deep) hipLaunchKernelGGL((gemm_loop_kernel<WT, KVT, MTv, NT, EPI, DMAX>), grid, dim3(256), pad, st, a); \
   else if (roll) hipLaunchKernelGGL((gemm_loop_kernel<WT, KVT, MTv, NT, EPI, 2>), grid, dim3(256), pad, st, a);     \
   else hipLaunchKernelGGL((gemm_tile_kernel<WT, KVT, MTv, NT, EPI>), grid, dim3(256), pad, st, a);
-  if (MT == 4) { DSM_LAUNCH_TILED(4) } else if (MT == 2) { DSM_LAUNCH_TILED(2) } else { DSM_LAUNCH_TILED(1) }
+#define DSM_LAUNCH_BX3(MTv)                                                                                     \
+  if (a.chunk_loop > 1) hipLaunchKernelGGL((gemm_bx3_kernel<KVT, MTv, NT, EPI, true>), grid, dim3(256), pad, st, a); \
+  else hipLaunchKernelGGL((gemm_bx3_kernel<KVT, MTv, NT, EPI, false>), grid, dim3(256), pad, st, a);
+  if (bx3 && EPI != EPI_RVQ) {
+    if (MT == 4) { DSM_LAUNCH_BX3(4) } else if (MT == 2) { DSM_LAUNCH_BX3(2) } else { DSM_LAUNCH_BX3(1) }
+  } else if (MT == 4) { DSM_LAUNCH_TILED(4) } else if (MT == 2) { DSM_LAUNCH_TILED(2) } else { DSM_LAUNCH_TILED(1) }
+#undef DSM_LAUNCH_BX3
 #undef DSM_LAUNCH_TILED
   const bool rows_ok = (EPI == EPI_STORE) && a.norm_out && a.vec && !a.Y2 && a.Y && a.N <= 4096 && a.ymap.bstride == 0;
   if (chunks > 1 && !(EPI == EPI_QKV && a.defer_reduce)) {
@@ -1011,8 +1020,12 @@ int launch_gemm_t(dsm_engine* e, hipStream_t st, GemmArgs& a, bool aligned) {
   dim3 grid(nx, (a.M + 16 * MT - 1) / (16 * MT));
   dim3 block(64 * S);
   size_t lds = chunks > 1 ? (size_t)chunks * NT * MT * 1024 : 0;
-#define DSM_LAUNCH(MTv, AL) \
-  hipLaunchKernelGGL((gemm_mfma_kernel<WT, KVT, MTv, NT, EPI, AL>), grid, block, lds, st, a)
+  const bool bx3 = e->dot_mode == 1 && sizeof(WT) == 2 && EPI != EPI_RVQ;
+#define DSM_LAUNCH(MTv, AL)                                                                                   \
+  do {                                                                                                        \
+    if (bx3) hipLaunchKernelGGL((gemm_mfma_kernel<WT, KVT, MTv, NT, EPI, AL, true>), grid, block, lds, st, a); \
+    else hipLaunchKernelGGL((gemm_mfma_kernel<WT, KVT, MTv, NT, EPI, AL>), grid, block, lds, st, a);          \
+  } while (0)
   const int ph = e->prof_begin(e->tag_gemm[e->sid(st)], st);
   if (MT == 1) {
     if (aligned) DSM_LAUNCH(1, true); else DSM_LAUNCH(1, false);

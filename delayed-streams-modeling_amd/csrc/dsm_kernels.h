@@ -18,6 +18,7 @@
 #include "dsm_sampling.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short dsm_bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ float wave_sum64(float v) {
 #pragma unroll
@@ -278,7 +279,7 @@ __device__ __forceinline__ void epi_rvq(const GemmArgs& a, f32x4 v, int m, int n
 // ---- generic GEMM (any K, any X alignment): one workgroup = S waves, wave w accumulates K-chunks w, w+S, ...
 // and parks each chunk's partial tile in LDS; the partials are summed left to right.  Used for the few layers
 // the tiled kernel below cannot take (K % 32 != 0 or unaligned rows: the 1-channel input conv, tiny test models).
-template <typename WT, typename KVT, int MT, int NT, int EPI, bool XALIGNED>
+template <typename WT, typename KVT, int MT, int NT, int EPI, bool XALIGNED, bool BX3 = false>
 __global__ void gemm_mfma_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds_part[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, S = blockDim.x >> 6;
@@ -320,6 +321,28 @@ __global__ void gemm_mfma_kernel(GemmArgs a) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) xb[mt][j] = (kb + 8 * q + j < a.K) ? xrow[mt][kb + j] : 0.0f;
         }
+      }
+      if (BX3) {  // dot_mode 1: three bf16 pieces of the activations against the bf16 weights (gemm_bx3_kernel's order)
+        dsm_bf16x8 wv[NT], xp[3][MT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) wv[nt][j] = (short)(__float_as_uint(wa[nt][j]) >> 16);  // the weights are bf16 values
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            uint16_t h, m, l;
+            dsm_split3(xb[mt][j], &h, &m, &l);
+            xp[0][mt][j] = (short)l; xp[1][mt][j] = (short)m; xp[2][mt][j] = (short)h;
+          }
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[nt], xp[p][mt], acc[nt][mt], 0, 0, 0);
+        continue;
       }
 #pragma unroll
       for (int s = 0; s < 8; ++s)
@@ -706,6 +729,137 @@ __global__ __launch_bounds__(256, OCC) void gemm_loop_kernel(GemmArgs a) {
         else
           epi_store_qkv<KVT, EPI>(a, tot[nt][mt], m, n);
       }
+    }
+  }
+  launch_stamp_end(a.ts);
+}
+
+// ---- dot_mode 1 ("bx3"): the bf16-weight GEMMs on v_mfma_f32_16x16x32_bf16 (r03) -------------------------------------------
+// Same tile, same grid, same slabs / epilogues as gemm_tile_kernel and gemm_loop_kernel — only the dot product of a K-chunk
+// differs: per 32-wide block  acc = mfma(w, x_lo, acc); acc = mfma(w, x_mid, acc); acc = mfma(w, x_hi, acc)  with x = hi + mid +
+// lo the exact three-bf16 split of dsm_split3 (every product exact; the instruction's adder: dsm_bf16_mfma_model.h, restated
+// by the oracle's orc_linear_bx3).  3 x 16 matrix-pipe cycles per 32 k and tile instead of 8 x 32, and the matrix pipe no
+// longer holds the vector ALU (experiments/fused_roles_probe.hip).  The activation block is split while it is staged: LDS holds
+// three bf16 planes [16 MT rows][32 k] (64-byte rows, 16-byte units XOR-swizzled by bits 1-2 of the row), double-buffered, one
+// barrier per block; weights go from HBM to the A operand as they are (eight bf16 = one 16-byte load per lane and block).
+// LOOP: one workgroup walks every K-chunk (grid.y = 1) and adds the chunk sums left to right in registers; otherwise
+// blockIdx.y is the chunk and, with more than one, the partial tile goes to the split-K slab.
+template <typename KVT, int MT, int NT, int EPI, bool LOOP>
+__global__ __launch_bounds__(256, 2) void gemm_bx3_kernel(GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) uint16_t Xp[2][3][16 * MT][32];
+  launch_stamp_begin(a.ts);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int chunks = LOOP ? 1 : (int)gridDim.y;
+  const int m_base = blockIdx.z * (16 * MT);
+  const int n_base = blockIdx.x * 64 + 16 * wave;
+  const uint16_t* W = reinterpret_cast<const uint16_t*>(a.W);
+  const uint16_t* wrow[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) wrow[nt] = W + (long)(n_base + nt * a.nt_stride + r) * a.Kpad + 8 * q;
+  constexpr int PIECES = 16 * MT * 8;
+  constexpr bool TWO = PIECES > 256;
+  const bool has0 = tid < PIECES;
+  const int row0 = has0 ? (tid >> 3) : 0, part = tid & 7;
+  int m0 = m_base + row0;
+  m0 = m0 < a.M ? m0 : a.M - 1;
+  const float* xsrc0 = a.X + a.xmap.off(m0) + 4 * part;
+  int m1 = m_base + row0 + 32;
+  m1 = m1 < a.M ? m1 : a.M - 1;
+  const float* xsrc1 = a.X + a.xmap.off(m1) + 4 * part;
+  // four consecutive k of one row -> 8 bytes in each plane
+  auto stage = [&](int buf, const float4& v, int row) {
+    uint16_t h[4], m[4], l[4];
+    dsm_split3(v.x, &h[0], &m[0], &l[0]); dsm_split3(v.y, &h[1], &m[1], &l[1]);
+    dsm_split3(v.z, &h[2], &m[2], &l[2]); dsm_split3(v.w, &h[3], &m[3], &l[3]);
+    const int off = row * 32 + (((part >> 1) ^ ((row >> 1) & 3)) * 8) + (part & 1) * 4;
+    *reinterpret_cast<uint2*>(&Xp[buf][0][0][0] + off) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+    *reinterpret_cast<uint2*>(&Xp[buf][1][0][0] + off) = make_uint2((uint32_t)m[0] | ((uint32_t)m[1] << 16), (uint32_t)m[2] | ((uint32_t)m[3] << 16));
+    *reinterpret_cast<uint2*>(&Xp[buf][2][0][0] + off) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+  };
+  const int kb0 = LOOP ? 0 : (int)blockIdx.y * (DSM_KC >> 5);
+  const int kb1 = LOOP ? (a.Kpad >> 5) : min(kb0 + (DSM_KC >> 5), a.Kpad >> 5);
+  f32x4 acc[NT][MT], tot[NT][MT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      tot[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  float4 xa = *reinterpret_cast<const float4*>(xsrc0 + 32 * kb0);
+  float4 xb = TWO ? *reinterpret_cast<const float4*>(xsrc1 + 32 * kb0) : xa;
+  uint4 wv[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) wv[nt] = *reinterpret_cast<const uint4*>(wrow[nt] + 32 * kb0);
+  for (int g = kb0; g < kb1; ++g) {
+    const int buf = (g - kb0) & 1;
+    if (has0) stage(buf, xa, row0);
+    if (TWO) stage(buf, xb, row0 + 32);
+    dsm_bf16x8 wa[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const uint4 w = wv[nt];
+      wa[nt][0] = (short)(w.x & 0xFFFF); wa[nt][1] = (short)(w.x >> 16); wa[nt][2] = (short)(w.y & 0xFFFF); wa[nt][3] = (short)(w.y >> 16);
+      wa[nt][4] = (short)(w.z & 0xFFFF); wa[nt][5] = (short)(w.z >> 16); wa[nt][6] = (short)(w.w & 0xFFFF); wa[nt][7] = (short)(w.w >> 16);
+    }
+    {  // the next block's loads fly behind this block's MFMAs (clamped to the last block: loaded again, never used)
+      const int gn = g + 1 < kb1 ? g + 1 : g;
+      xa = *reinterpret_cast<const float4*>(xsrc0 + 32 * gn);
+      if (TWO) xb = *reinterpret_cast<const float4*>(xsrc1 + 32 * gn);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) wv[nt] = *reinterpret_cast<const uint4*>(wrow[nt] + 32 * gn);
+    }
+    __syncthreads();  // block g's planes are complete; buffer buf ^ 1 was last read before the previous barrier
+#pragma unroll
+    for (int p = 0; p < 3; ++p)  // canonical order of the pieces: lo, mid, hi
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int row = 16 * mt + r;
+        const dsm_bf16x8 xf = *reinterpret_cast<const dsm_bf16x8*>(&Xp[buf][p][0][0] + row * 32 + ((q ^ ((row >> 1) & 3)) * 8));
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[nt], xf, acc[nt][mt], 0, 0, 0);
+      }
+    if (LOOP && ((g & 7) == 7 || g == kb1 - 1)) {  // a 256-wide chunk is complete: canonical left-to-right chunk sum
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          tot[nt][mt] = tot[nt][mt] + acc[nt][mt];  // first chunk: +0 + acc (the oracle does the same)
+          acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+  }
+  if (!LOOP) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) tot[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f} + acc[nt][mt];  // +0 + chunk sum, as above
+  }
+  if (chunks > 1) {
+    const long ld = (long)a.ws_ntiles * 16;
+    const long mpad = (long)((a.M + 15) >> 4) * 16;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = m_base + 16 * mt + r;
+      if (m >= mpad) continue;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n = n_base + nt * a.nt_stride + 4 * q;
+        *reinterpret_cast<f32x4*>(a.ws + ((long)blockIdx.y * mpad + m) * ld + n) = tot[nt][mt];
+      }
+    }
+    launch_stamp_end(a.ts);
+    return;
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m_base + 16 * mt + r;
+    if (EPI == EPI_GATE) {
+      epi_gate(a, tot[0][mt], tot[NT - 1][mt], m, n_base + 4 * q);
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) epi_store_qkv<KVT, EPI>(a, tot[nt][mt], m, n_base + nt * a.nt_stride + 4 * q);
     }
   }
   launch_stamp_end(a.ts);

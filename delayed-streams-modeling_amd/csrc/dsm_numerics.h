@@ -52,6 +52,20 @@ DSM_HD uint16_t dsm_f32_to_bf16(float f) {
 
 #define DSM_INF_F (dsm_u32_as_f32(0x7F800000u))
 
+/* dot_mode 1 ("bx3"): x = hi + mid + lo exactly, three bf16 pieces of 8 significand bits each — hi = x with the low 16 bits
+ * of its pattern cleared, mid the same of x - hi (exact), lo = x - hi - mid (exact, at most 8 significant bits left).
+ * Returned as bf16 bit patterns.  (Pieces of a value below 2^-110 may be bf16 subnormals; the matrix instruction takes
+ * them at face value, csrc/dsm_bf16_mfma_model.h.) */
+DSM_HD void dsm_split3(float x, uint16_t* hi, uint16_t* mid, uint16_t* lo) {
+  const uint32_t u = dsm_f32_as_u32(x);
+  const float r1 = x - dsm_u32_as_f32(u & 0xFFFF0000u);
+  const uint32_t u1 = dsm_f32_as_u32(r1);
+  const float r2 = r1 - dsm_u32_as_f32(u1 & 0xFFFF0000u);
+  *hi = (uint16_t)(u >> 16);
+  *mid = (uint16_t)(u1 >> 16);
+  *lo = (uint16_t)(dsm_f32_as_u32(r2) >> 16);
+}
+
 /* e^x, ~1 ulp, flushes to 0 below -87.3 (keeps every result normal or zero, so the
  * function does not depend on the denormal mode of either machine). */
 DSM_HD float dsm_expf(float x) {

@@ -91,6 +91,14 @@ typedef struct dsm_asr_config {
   /* engine numerics: 1 = K/V ring cache stored as bf16 (GPU target, BASELINE.md roofline),
    * 0 = f32 cache (the Candle CPU path's dtype, srv/utils.rs:386-395). */
   int kv_bf16;
+  /* how the bf16-weight linear layers (the LM's GEMMs) form their dot products — both orders are restated bit for bit by the
+   * oracle (oracle/dsm_oracle.c orc_dot), neither is Candle's (whose gemm order is implementation-defined):
+   *   0  v_mfma_f32_16x16x4_f32: one f32 fmaf chain per 256-wide K-chunk (csrc/dsm_numerics.h)
+   *   1  "bx3" (r03): the f32 activation split exactly into three bf16 pieces, v_mfma_f32_16x16x32_bf16 on (weight, piece)
+   *      per 32-wide block in the order lo, mid, hi; the instruction's internal adder as modelled in
+   *      csrc/dsm_bf16_mfma_model.h (validated on the hardware: experiments/bf16_adder_probe.hip).  Every product is exact; the
+   *      matrix pipe does a third of the cycles per k ... at 16 x the rate */
+  int dot_mode;
 } dsm_asr_config;
 
 /* Presets matching configs/stt/config-stt-en_fr-hf.toml and config-stt-en-hf.toml. */
@@ -287,6 +295,7 @@ typedef struct dsm_tts_config {
   int ca_dim;            /* width of a cross-attention source row (kv_in_dim, cfg.cross_attention.2); 0 = d_model */
   int ca_max_len;        /* longest source (rows of ca_src) a slot may be given with dsm_tts_set_ca_src */
   int cfg_rows;          /* 1: every slot owns TWO batch rows (conditional, unconditional) so that it can run with a cfg_alpha */
+  int dot_mode;          /* as dsm_asr_config.dot_mode */
 } dsm_tts_config;
 void dsm_tts_config_v202501(dsm_tts_config* out); /* Config::v202501 + configs/tts/config-tts.toml with a consistent depformer */
 

@@ -101,6 +101,12 @@ float orc_bf16_to_f32(uint16_t h);
 }
 #endif
 
+/* dot_mode 1 ("bx3"): the header's reference statement of v_mfma_f32_16x16x32_bf16 and the oracle's fast form of one group */
+uint32_t orc_bf16_mfma32(uint32_t c_bits, const uint16_t* a /*[32]*/, const uint16_t* b /*[32]*/);
+uint32_t orc_bx3_group8(uint32_t v_bits, const uint16_t* a /*[8]*/, const uint16_t* b /*[8]*/);
+void orc_linear_mode(int mode);
+
+
 /* ---- TTS step (config 5): see oracle/dsm_oracle_tts.inc ---- */
 #ifdef __cplusplus
 extern "C" {
