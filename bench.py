@@ -36,6 +36,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64, help="stream slots per GPU")
     ap.add_argument("--config", default="stt-1b-en_fr", choices=["stt-1b-en_fr", "stt-2.6b-en", "tiny"])
+    ap.add_argument("--dot-mode", type=int, default=1, choices=[0, 1],
+                    help="dsm_asr_config.dot_mode of the timed engine.  1 (bench default): the LM's bf16-weight GEMMs on v_mfma_f32_16x16x32_bf16 "
+                         "over the exact three-way bf16 split of the f32 activations; 0 (the config constructors' default): the f32 fmaf "
+                         "chain on v_mfma_f32_16x16x4_f32.  Each mode is bit-exact against the oracle run in the same mode; the other "
+                         "mode's step time is reported beside the headline as `other_dot_mode`")
     ap.add_argument("--spawn-check-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)      # tests: this rank raises mid-run
     ap.add_argument("--spawn-check-arena-skew-rank", type=int, default=-1, help=argparse.SUPPRESS)  # tests: this rank reports another arena size
     ap.add_argument("--host-path-legs", default="400,2048",
@@ -68,6 +73,10 @@ def cpu_baseline(cfg, B, lm_path, mimi_path, n_steps):
     import oracle
     from dsm_amd import synth
     oracle.build()
+    # timed in dot_mode 0 whatever the GPU line runs: mode 0 is plain f32 fused multiply-adds, what a CPU implementation of the
+    # reference path does; mode 1's restatement emulates the GPU's bf16 matrix instruction in integers — a checker, not a baseline
+    cfg = type(cfg).from_buffer_copy(cfg)
+    cfg.dot_mode = 0
     t0 = time.time()
     o = oracle.OracleAsr(cfg, B, lm_path, mimi_path)
     load_s = time.time() - t0
@@ -85,7 +94,7 @@ def cpu_baseline(cfg, B, lm_path, mimi_path, n_steps):
             "cores": cores, "kind": "port",
             "sample": f"{n_steps} frame(s) x {B} streams on full rings ({cfg.lm.context} LM / {cfg.mimi.transformer.context} Mimi frames, "
                       f"the steady state the GPU line is timed in), {dt * 1000:.0f} ms/step, oracle load {load_s:.0f} s; "
-                      "Candle itself cannot be built offline"}
+                      "dot_mode 0 (f32 fma dot products); Candle itself cannot be built offline"}
 
 
 def bench_decode(args, eng, cfg, B, dev, world, rank, dist, torch):
@@ -298,6 +307,7 @@ def main():
 
     cfg = {"stt-1b-en_fr": dsm_amd.config_stt_1b_en_fr, "stt-2.6b-en": dsm_amd.config_stt_2_6b_en,
            "tiny": dsm_amd.config_tiny}[args.config]()
+    cfg.dot_mode = args.dot_mode
     B = args.batch
     tag = args.config
     # rank 0 writes + loads the synthetic checkpoint; the other ranks receive the packed device weight arena over RCCL
@@ -407,6 +417,18 @@ def main():
                 legs[Bl] = {"error": str(ex)[:200]}
             torch.cuda.empty_cache()
 
+    # the same batch in the other dot_mode (same weight arena, steady-state ring positions, 30 timed steps)
+    other_mode = None
+    if world == 1 and args.config != "tiny" and args.part == "all" and not args.no_overlap:
+        try:
+            ocfg = type(cfg).from_buffer_copy(cfg)
+            ocfg.dot_mode = 1 - args.dot_mode
+            oms = capacity_leg(dsm_amd, synth, ocfg, B, eng.weight_arena(), dev, local_rank, 30, torch)
+            other_mode = {"dot_mode": ocfg.dot_mode, "ms_per_step": oms, "value": B * 80.0 / oms}
+        except Exception as ex:
+            other_mode = {"error": str(ex)[:200]}
+        torch.cuda.empty_cache()
+
     # ---- host-path legs (N = 1 only): the same batches driven end to end from HOST audio through the worker — per-channel
     # msgpack InMsg::Audio decode, the reference's encoder / model thread split with run-ahead, pinned staging + H2D, LM step,
     # OutMsg::Step fan-out and drain (tools/host_path_bench.cpp).  VERDICT r02 #5: the device-resident legs above say nothing
@@ -475,7 +497,9 @@ def main():
             # on 1x NVIDIA L40S (reference README.md:73-74) — other hardware, quoted for scale only
             "vs_baseline": (B * 0.08 / (ms_per_step / 1000.0)) / 192.0 if (args.config == "stt-1b-en_fr" and B == 64) else None,
             "baseline": "64 streams @ 3x real time (192 x realtime) on 1x L40S, per GPU (BASELINE.md)",
-            "dtype": "bf16 weights + bf16 KV, f32 activations/accumulate", "data": "synthetic",
+            "dtype": ("bf16 weights + bf16 KV, f32 activations as three exact bf16 pieces, f32 accumulate (v_mfma_f32_16x16x32_bf16)"
+                      if args.dot_mode == 1 else "bf16 weights + bf16 KV, f32 activations/accumulate (v_mfma_f32_16x16x4_f32)"),
+            "data": "synthetic", "dot_mode": args.dot_mode, "other_dot_mode": other_mode,
             "rtf": 80.0 / ms_per_step,
             "config": {"workload": "%s batch=%d streaming, ring KV cache full (%d frames), Mimi encode + LM decode HIP path"
                                    % (args.config, B, fill),

@@ -84,6 +84,12 @@ def load_batched_asr(path, module=None):
     if dt not in (None, "bf16", "f32"):
         raise ConfigError(f"dtype_override {dt!r}: only bf16 and f32 exist on this engine")
     cfg.kv_bf16 = 0 if dt == "f32" else 1
+    # extension key of this engine (absent in the reference's tomls): which canonical dot product the bf16-weight GEMMs use
+    # (include/dsm.h, dsm_asr_config.dot_mode); 0 unless the deployment opts in
+    dm = m.get("dot_mode", 0)
+    if dm not in (0, 1):
+        raise ConfigError(f"dot_mode {dm!r}: 0 (f32 fma chain) or 1 (bf16 matrix instruction over the exact three-way split)")
+    cfg.dot_mode = int(dm)
     # Mimi: Config::v0_1(Some(audio_codebooks)) — srv/batched_asr.rs:754
     load_library().dsm_mimi_config_v0_1(C.byref(cfg.mimi), cfg.audio_codebooks)
     host = {k: m.get(k) for k in ("path", "lm_model_file", "text_tokenizer_file", "audio_tokenizer_file", "batch_size",

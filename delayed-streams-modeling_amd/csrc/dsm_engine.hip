@@ -206,6 +206,8 @@ struct dsm_engine {
   bool stagger = true;  // DSM_STAGGER=0: every group starts its step at once (r01); 2: staggered at every batch size
   bool stagger_force = false;
   bool grp_busy = false;
+  int enc_cus = 0;            // DSM_ENC_CUS: CUs per XCD for the encoder stream (0: no CU mask)
+  bool lm_cus_excl = false;   // DSM_LM_CUS_EXCL=1: the LM streams get the complement
   bool fuse_qkv = true;  // DSM_FUSE_QKV=0: keep the separate QKV reduce launch
   bool chunk_loop = true;  // DSM_CHUNK_LOOP=0: always split K across workgroups
   bool roll_prefetch = true;  // DSM_ROLL=0: the chunk loop requests a chunk only after finishing the previous one (r01 behaviour)
