@@ -137,6 +137,7 @@ def bench_tts(args, world, rank, local_rank):
     import dsm_amd
     from dsm_amd import synth
     cfg = dsm_amd.config_tts_v202501()
+    cfg.dot_mode = args.dot_mode
     B = args.batch
     path = synth.make_synth_tts_weights(cfg, args.weights_dir, tag="tts-v202501" + ("" if world == 1 else f".rank{rank}"))
     eng = dsm_amd.TtsEngine(cfg, B, path, device_id=local_rank)
@@ -167,12 +168,29 @@ def bench_tts(args, world, rank, local_rank):
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     ms = float(dt.item()) / args.steps * 1000
     if rank == 0:
+        m = eng.metrics()
+        wbytes = m.algorithmic_bytes_lm
+        achieved = wbytes / (ms * 1e-3) / 1e9
         print(json.dumps({"metric": "TTS step real-time generation throughput @ bs=%d" % B, "value": world * B * 0.08 / (ms / 1000),
                           "unit": "x realtime (seconds of audio tokens per wall second)", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                          "dtype": "f32 accumulate, bf16 weights", "data": "synthetic", "rtf": 80.0 / ms,
+                          "dtype": ("bf16 weights, f32 activations as three exact bf16 pieces, f32 accumulate" if args.dot_mode == 1
+                                    else "bf16 weights, f32 activations/accumulate"),
+                          "data": "synthetic", "rtf": 80.0 / ms, "dot_mode": args.dot_mode,
                           "config": {"workload": "tts v202501 State::step (2048-d x 16 LM + 32-slice depformer, greedy), batch=%d, "
-                                                 "KV fill %d frames" % (B, fill + args.warmup)}}))
+                                                 "KV fill %d frames" % (B, fill + args.warmup)},
+                          # the step is one dependent chain of ~1400 launches of 4-7 us (profiles/r03/tts_kernel_trace_summary.txt):
+                          # no kernel dominates, so the roofline object prices the WHOLE step against the bytes it has to stream
+                          "roofline": {"bound": "hbm", "kernel": "whole step (launch-bound chain: 16 LM layers + 32 depformer slices x 4 layers, "
+                                                                  "every GEMM / reduce / attention launch 4-22 us at %d rows)" % B,
+                                       "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                                       "algorithmic_bytes_per_launch": wbytes,
+                                       "what": "bf16 weight matrices multiplied per step, each counted once (dsm_tts_get_metrics); "
+                                               "embedding rows and the short KV reads left out",
+                                       "avg_launch_us": ms * 1000.0, "timer": "host wall clock over the timed steps (each step synchronises)",
+                                       "traffic": None},
+                          "graphs": {"graph_launches": int(m.graph_launches), "eager_bodies": int(m.eager_bodies),
+                                     "capture_failures": int(m.capture_failures)}}))
     eng.close()
 
 
@@ -440,7 +458,7 @@ def main():
             try:
                 if not os.path.exists(exe):
                     raise RuntimeError("tools/host_path_bench is not built (__graft_entry__.build())")
-                r = subprocess.run([exe, lm_path, mimi_path, str(Bl), str(args.host_path_frames), "8"], capture_output=True, text=True, timeout=240)
+                r = subprocess.run([exe, lm_path, mimi_path, str(Bl), str(args.host_path_frames), "8", str(args.dot_mode)], capture_output=True, text=True, timeout=240)
                 if r.returncode != 0:
                     raise RuntimeError((r.stderr or r.stdout)[-200:])
                 host_legs[Bl] = json.loads(r.stdout.strip().splitlines()[-1])
@@ -464,7 +482,7 @@ def main():
         # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (bench.py cannot run under --pmc and
         # time itself): 2 x FETCH_SIZE (gfx950 counts 64 B per 128-B request) + WRITE_SIZE, per dispatch
         traffic, traffic_src = None, None
-        for rnd in ("r02", "r01"):
+        for rnd in ("r03", "r02", "r01"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", rnd, "pmc_hbm_traffic.json")))
                 for k in pmc["kernels"]:

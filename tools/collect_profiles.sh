@@ -18,6 +18,12 @@ for t in trace_1stream:kernel_stats_single_stream trace:kernel_stats_overlapped;
 done
 python3 tools/trace_summary.py $P/trace_1stream 14 > $D/kernel_trace_single_stream_summary.txt
 python3 tools/trace_summary.py $P/trace 14 > $D/kernel_trace_overlapped_summary.txt
+if [ -d $P/trace_tts ]; then
+  f=$(ls -t $P/trace_tts/*/*_kernel_stats.csv | head -1)
+  cp "$f" $D/tts_kernel_stats.csv
+  grep '^{' $P/trace_tts_bench.json > $D/tts_kernel_stats.bench.json || true
+  python3 tools/trace_table.py $P/trace_tts > $D/tts_kernel_trace_summary.txt
+fi
 if [ -d $P/extra ]; then
   mkdir -p $D/extra
   for f in $P/extra/*.json; do grep '^{' "$f" > $D/extra/$(basename "$f") || true; done

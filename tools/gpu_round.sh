@@ -36,6 +36,13 @@ step b2048_lm_g1 200 bash -c "DSM_LM_GROUPS=1 $C --part lm > $X/b2048_lm_one_gro
 step b2048_1s 200 bash -c "$C --no-overlap > $X/b2048_single_stream.json 2> $X/b2048_1s.err"
 step b26 300 bash -c "python bench.py --config stt-2.6b-en --batch 128 --fast-fill --steps 50 --warmup 5 --no-cpu-baseline --capacity-legs '' > $X/bench_stt_2.6b_b128.json 2> $X/b26.err"
 step tts 200 bash -c "python bench.py --workload tts --batch 32 --steps 50 --warmup 5 --no-cpu-baseline --capacity-legs '' > $X/bench_tts_b32.json 2> $X/tts.err"
+step tts_m0 200 bash -c "python bench.py --workload tts --batch 32 --steps 50 --warmup 5 --dot-mode 0 > $X/bench_tts_b32_dot_mode0.json 2> $X/tts_m0.err"
+step tts_trace 300 rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace_tts -- python3 bench.py --workload tts --batch 32 --steps 30 --warmup 3 > $P/trace_tts_bench.json 2> $P/trace_tts.err
+step b64_m0 300 bash -c "python bench.py --fast-fill --dot-mode 0 --no-cpu-baseline --host-path-legs '' --capacity-legs 400,2048 > $X/bench_b64_dot_mode0.json 2> $X/b64_m0.err"
+if [ -x experiments/gemm_m64_probe ]; then
+  step m64probe 200 rocprofv3 --kernel-trace --output-format csv -d $P/m64probe -- ./experiments/gemm_m64_probe > $X/gemm_m64_probe.out 2>&1
+  python3 tools/trace_table.py $P/m64probe probe > $X/gemm_m64_probe.txt
+fi
 if [ -x experiments/corun_probe ]; then step corun 200 bash -c "./experiments/corun_probe 8192 > $X/corun_probe.txt 2>&1"; fi
 if [ -x experiments/queue_probe ]; then step queue 100 bash -c "./experiments/queue_probe > $X/queue_probe.txt 2>&1"; fi
 python3 tools/trace_summary.py $P/trace_1stream 14

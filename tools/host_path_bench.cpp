@@ -12,7 +12,7 @@
 // the per-thread busy times say which side is the limit.  Ring caches are jumped to the steady state first
 // (dsm_debug_set_positions), like the device-resident legs.
 //
-// usage: host_path_bench <lm.safetensors> <mimi.safetensors> <batch> <frames> [feeder threads = 8]   (stt-1b-en_fr)
+// usage: host_path_bench <lm.safetensors> <mimi.safetensors> <batch> <frames> [feeder threads = 8] [dot_mode = 0]   (stt-1b-en_fr)
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -31,6 +31,7 @@ int main(int argc, char** argv) {
   const int B = atoi(argv[3]), frames = atoi(argv[4]), F = argc > 5 ? atoi(argv[5]) : 8;
   dsm_asr_config cfg;
   dsm_asr_config_stt_1b_en_fr(&cfg);
+  cfg.dot_mode = argc > 6 ? atoi(argv[6]) : 0;
   dsm_engine* e = nullptr;
   if (dsm_asr_create(&cfg, 0, B, argv[1], argv[2], &e)) { fprintf(stderr, "create: %s\n", dsm_last_error(nullptr)); return 2; }
   dsm_worker* w = nullptr;
@@ -118,10 +119,10 @@ int main(int argc, char** argv) {
   dsm_metrics mt;
   dsm_get_metrics(e, &mt);
   const double ms_frame = wall / frames;
-  printf("{\"batch\": %d, \"frames\": %d, \"feeder_threads\": %d, \"ms_per_frame\": %.3f, \"rtf\": %.3f, "
+  printf("{\"batch\": %d, \"dot_mode\": %d, \"frames\": %d, \"feeder_threads\": %d, \"ms_per_frame\": %.3f, \"rtf\": %.3f, "
          "\"feed_ms_per_frame\": %.3f, \"encoder_thread_ms_per_frame\": %.3f, \"model_thread_ms_per_frame\": %.3f, "
          "\"recv_ms_per_frame\": %.3f, \"wire_bytes_per_frame\": %zu, \"graph_launches\": %llu, \"capture_failures\": %llu}\n",
-         B, frames, F, ms_frame, 80.0 / ms_frame, t_feed / frames, t_enc / frames, t_model / frames, t_recv / frames,
+         B, cfg.dot_mode, frames, F, ms_frame, 80.0 / ms_frame, t_feed / frames, t_enc / frames, t_model / frames, t_recv / frames,
          wire[0].size() * (size_t)B, (unsigned long long)mt.graph_launches, (unsigned long long)mt.capture_failures);
   dsm_worker_destroy(w);
   dsm_destroy(e);
