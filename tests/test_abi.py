@@ -23,7 +23,7 @@ def test_struct_sizes_match_the_header(dsm, lib):
     # int-only structs: sizes follow from the field counts in include/dsm.h
     assert C.sizeof(dsm.TransformerConfig) == 11 * 4
     assert C.sizeof(dsm.MimiConfig) == (5 + 8 + 5) * 4 + 11 * 4 + 4 * 4
-    assert C.sizeof(dsm.AsrConfig) == 11 * 4 + 8 * 4 + C.sizeof(dsm.MimiConfig) + 4
+    assert C.sizeof(dsm.AsrConfig) == 11 * 4 + 8 * 4 + C.sizeof(dsm.MimiConfig) + 4 + 4  # ... kv_bf16, dot_mode (r03)
 
 
 def test_presets_match_the_shipped_tomls(dsm, lib):
