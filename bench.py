@@ -43,7 +43,7 @@ def parse():
                          "mode's step time is reported beside the headline as `other_dot_mode`")
     ap.add_argument("--spawn-check-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)      # tests: this rank raises mid-run
     ap.add_argument("--spawn-check-arena-skew-rank", type=int, default=-1, help=argparse.SUPPRESS)  # tests: this rank reports another arena size
-    ap.add_argument("--host-path-legs", default="400,2048",
+    ap.add_argument("--host-path-legs", default="400,2048,2304",
                     help="batch sizes for the end-to-end host-path legs (tools/host_path_bench: msgpack in, worker threads, H2D, "
                          "msgpack out); empty = skip")
     ap.add_argument("--host-path-frames", type=int, default=16)
@@ -554,11 +554,7 @@ def main():
             if host_legs:
                 # what can be promised: the largest measured batch whose RTF keeps a 10 % margin on BOTH the device-resident step
                 # and (where it was driven) the whole host path
-                def rtf_of(b):
-                    r = legs[b].get("rtf", 0.0)
-                    h = host_legs.get(b, {}).get("rtf")
-                    return min(r, h) if h is not None else r
-                safe = [b for b in legs if "rtf" in legs[b] and rtf_of(b) >= 1.10]
+                safe = [b for b in legs if legs[b].get("rtf", 0.0) >= 1.10 and host_legs.get(b, {}).get("rtf", 0.0) >= 1.10]
                 out["capacity"]["host_path"] = {
                     "legs": {str(b): v for b, v in host_legs.items()},
                     "what": "end to end from host audio: msgpack InMsg::Audio per channel (8 feeder threads) -> dsm_worker_send -> "

@@ -38,6 +38,11 @@ step b26 300 bash -c "python bench.py --config stt-2.6b-en --batch 128 --fast-fi
 step tts 200 bash -c "python bench.py --workload tts --batch 32 --steps 50 --warmup 5 --no-cpu-baseline --capacity-legs '' > $X/bench_tts_b32.json 2> $X/tts.err"
 step tts_m0 200 bash -c "python bench.py --workload tts --batch 32 --steps 50 --warmup 5 --dot-mode 0 > $X/bench_tts_b32_dot_mode0.json 2> $X/tts_m0.err"
 step tts_trace 300 rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace_tts -- python3 bench.py --workload tts --batch 32 --steps 30 --warmup 3 > $P/trace_tts_bench.json 2> $P/trace_tts.err
+C64="python bench.py --fast-fill --steps 100 --warmup 10 --no-cpu-baseline --host-path-legs '' --capacity-legs ''"
+step b64_lm 200 bash -c "$C64 --part lm > $X/b64_lm.json 2> $X/b64_lm.err"
+step b64_enc 200 bash -c "$C64 --part enc > $X/b64_enc.json 2> $X/b64_enc.err"
+step b64_lm_g1 200 bash -c "DSM_LM_GROUPS=1 $C64 --part lm > $X/b64_lm_one_group.json 2> $X/b64_lm_g1.err"
+step b64_g1 200 bash -c "DSM_LM_GROUPS=1 $C64 > $X/b64_one_group.json 2> $X/b64_g1.err"
 step b64_m0 300 bash -c "python bench.py --fast-fill --dot-mode 0 --no-cpu-baseline --host-path-legs '' --capacity-legs 400,2048 > $X/bench_b64_dot_mode0.json 2> $X/b64_m0.err"
 if [ -x experiments/gemm_m64_probe ]; then
   step m64probe 200 rocprofv3 --kernel-trace --output-format csv -d $P/m64probe -- ./experiments/gemm_m64_probe > $X/gemm_m64_probe.out 2>&1

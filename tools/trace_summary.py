@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-(kernel, grid) summary of a rocprofv3 kernel-trace CSV; also prints the inter-kernel idle time."""
 import collections, csv, glob, os, sys
-f = max(glob.glob(sys.argv[1] + "/*/*_kernel_trace.csv"), key=os.path.getmtime)
+f = max(glob.glob(sys.argv[1] + "/*/*_kernel_trace.csv"), key=os.path.getsize)  # the bench process (child processes it spawns are traced too)
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 agg = collections.defaultdict(list)
 for r in rows:
@@ -12,8 +12,11 @@ for r in rows:
 tot = sum(sum(v) for v in agg.values())
 for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:int(sys.argv[2]) if len(sys.argv) > 2 else 40]:
     print(f"{k[0]:50s} grid={k[1]:5d}x{k[2]:4d}x{k[3]:4d} wg={k[4]:4d} n={len(v):5d} avg={sum(v)/len(v):7.1f}us share={sum(v)/tot*100:5.1f}%")
-# idle gaps inside the last 10 steps (between lm_input launches)
-idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("lm_input_kernel")]
+# idle gaps inside the last 10 steps: one conv_state_shift launch per Mimi encode = per step (lm_input runs once per stream
+# GROUP, i.e. twice per step by default — r02's summary counted half steps)
+idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("conv_state_shift_kernel")]
+if len(idx) <= 12:
+    idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("lm_input_kernel")]
 if len(idx) > 12:
     a, b = idx[-11], idx[-1]
     span = int(rows[b]["Start_Timestamp"]) - int(rows[a]["Start_Timestamp"])
