@@ -24,10 +24,11 @@ def schedule():
     return m
 
 
-def run(make_engine, mimi_reset):
+def run(make_engine, mimi_reset, dot_mode=0):
     import dsm_amd
     from dsm_amd import synth
     cfg = dsm_amd.config_tiny()
+    cfg.dot_mode = dot_mode  # 1: tests/golden/tiny_asr_dot_mode1.json (the bf16-matrix-instruction order)
     lm, mimi = synth.make_synth_weights(cfg, os.environ.get("DSM_WEIGHTS_DIR", "/tmp/dsm_weights"), tag="tiny")
     eng = make_engine(cfg, B, lm, mimi)
     pcm = synth.synth_pcm(B, STEPS)
@@ -75,8 +76,9 @@ if __name__ == "__main__":
     if "--tts" in sys.argv:
         run_tts()
         sys.exit(0)
-    res = run(oracle.OracleAsr, lambda e, slot: e.mimi_reset_batch_idx(slot, side=0))
-    path = os.path.join(ROOT, "tests", "golden", "tiny_asr.json")
+    mode = 1 if "--dot-mode-1" in sys.argv else 0
+    res = run(oracle.OracleAsr, lambda e, slot: e.mimi_reset_batch_idx(slot, side=0), dot_mode=mode)
+    path = os.path.join(ROOT, "tests", "golden", "tiny_asr_dot_mode1.json" if mode else "tiny_asr.json")
     with open(path, "w") as f:
         json.dump(res, f, separators=(",", ":"))
     print("wrote", path, os.path.getsize(path), "bytes")
