@@ -18,6 +18,7 @@
 #include <mutex>
 #include <shared_mutex>
 #include <string>
+#include <set>
 #include <vector>
 
 #include "../../include/dsm.h"
@@ -977,7 +978,7 @@ int launch_gemm_tiled(dsm_engine* e, hipStream_t st, GemmArgs& a) {
 #undef DSM_LAUNCH_BX3
 #undef DSM_LAUNCH_TILED
   const bool rows_ok = (EPI == EPI_STORE) && a.norm_out && a.vec && !a.Y2 && a.Y && a.N <= 4096 && a.ymap.bstride == 0;
-  if (chunks > 1 && !(EPI == EPI_QKV && a.defer_reduce)) {
+  if (chunks > 1 && !((EPI == EPI_QKV || EPI == EPI_STORE) && a.defer_reduce)) {  // deferred: the consumer sums the slabs (AttnFused, LogitSrc)
     if (rows_ok) {
       if (a.N <= 1024) hipLaunchKernelGGL(gemm_reduce_rows_kernel<1>, dim3(a.M), dim3(256), 0, st, a, chunks);
       else if (a.N <= 2048) hipLaunchKernelGGL(gemm_reduce_rows_kernel<2>, dim3(a.M), dim3(512), 0, st, a, chunks);

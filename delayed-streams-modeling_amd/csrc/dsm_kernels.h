@@ -1549,6 +1549,56 @@ __global__ void dep_gather_kernel(float* __restrict__ e, const float* __restrict
   for (int j = threadIdx.x; j < D / 4; j += blockDim.x) dst[j] = src[j];
 }
 
+// DepFormer slice head (r03): what dep_gather_kernel + the depformer_in GEMM's reduce/residual epilogue + kv_builder_kernel
+// (T = 1, no RoPE) + row_norm_kernel did in five launches, for one batch row per workgroup (256 threads):
+//   x  = emb_k[last token] + proj[row][g*D ...]   (core/lm.rs:655-661: depformer_in(xs) + emb; proj = ALL weight groups' input
+//        projections of the main LM's output, one GEMM per step — they do not depend on the slice)
+//   ring bookkeeping of ScatteredCacheBuilder for one new position (kv_builder_kernel's thread 0)
+//   xn = norm1 of layer 0 over x, canonical row reduction (row_norm_kernel's arithmetic)
+// `rv + o` of the GEMM epilogue is a single f32 add either way: same bits as the five launches.
+__global__ __launch_bounds__(256) void dep_head_kernel(float* __restrict__ x, float* __restrict__ xn,
+                                                       const float* __restrict__ table, const uint32_t* __restrict__ last_tok,
+                                                       int vocab, int D, int rps, const float* __restrict__ proj, long proj_ld,
+                                                       uint32_t* __restrict__ pos, uint32_t* __restrict__ idx,
+                                                       const uint8_t* __restrict__ active, uint32_t* __restrict__ start_pos,
+                                                       uint32_t* __restrict__ widx, int ctx, const float* __restrict__ nw,
+                                                       const float* __restrict__ nb, float eps, int rms) {
+  __shared__ float red[8];
+  const int b = blockIdx.x;
+  if (threadIdx.x == 0 && pos) {  // kv_builder_kernel, T = 1 (pos null: a rotary depformer runs the general builder instead)
+    const uint32_t p = pos[b], i = idx[b];
+    start_pos[b] = p;
+    widx[b] = i;  // active: (i + 0) % ctx = i (i < ctx); inactive: i
+    if (active[b]) {
+      pos[b] = p + 1;
+      idx[b] = (uint32_t)((i + 1) % ctx);
+    }
+  }
+  uint32_t t = last_tok[b / rps];
+  if (t >= (uint32_t)vocab) t = 0;
+  const float* er = table + (long)t * D;
+  const float* pr = proj + (long)b * proj_ld;
+  float4 v[DSM_ROW_ITS];
+  float s = 0.0f, s2 = 0.0f;
+#pragma unroll
+  for (int it = 0; it < DSM_ROW_ITS; ++it) {
+    const int i = it * 1024 + 4 * (int)threadIdx.x;
+    v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < D) {
+      const float4 ev = *reinterpret_cast<const float4*>(er + i);
+      const float4 pv = *reinterpret_cast<const float4*>(pr + i);
+      v[it] = make_float4(ev.x + pv.x, ev.y + pv.y, ev.z + pv.z, ev.w + pv.w);
+      *reinterpret_cast<float4*>(x + (long)b * D + i) = v[it];
+      s = s + v[it].x; s2 = DSM_FMAF(v[it].x, v[it].x, s2);
+      s = s + v[it].y; s2 = DSM_FMAF(v[it].y, v[it].y, s2);
+      s = s + v[it].z; s2 = DSM_FMAF(v[it].z, v[it].z, s2);
+      s = s + v[it].w; s2 = DSM_FMAF(v[it].w, v[it].w, s2);
+    }
+  }
+  block_row_sums(s, s2, red);
+  row_norm_apply(v, s, s2, D, eps, rms, nw, nb, xn + (long)b * D);
+}
+
 // Classifier-free guidance mix of a slot's two batch rows — core/tts_streaming.rs:166-172, core/lm.rs:718-721:
 //   ((l0 * a)? - (l1 * (a - 1.))?)?   with Tensor * f64 = affine(mul, 0.): v * (mul as f32) + 0f32 on the CPU backend.
 // out [B][V]; rows [B * 2][V]; slots without guidance copy row 0.  grid (ceil(V / 256), B).
@@ -1580,18 +1630,66 @@ __global__ void ca_kv_scatter_kernel(const float* __restrict__ kv, KVT* __restri
 
 // DepFormer::sample slice epilogue: lp.sample (ArgMax, or seeded top-k per slot), forced pre-delay pad for the NEXT
 // slice's input (:671-680)
-__global__ void dep_argmax_kernel(const float* __restrict__ logits, int V, int k, int S, uint32_t* __restrict__ lat,
+// Where a slot's logits come from (r03): the output GEMM's split-K slabs, summed here in canonical order (gemm_reduce_kernel's
+// arithmetic for a plain EPI_STORE: no bias, scale, residual), or the finished rows; with two batch rows per slot the
+// guidance mix of cfg_mix_kernel is applied on the way.  One launch instead of reduce + mix + sampler per depformer slice.
+struct LogitSrc {
+  const float* ws;    // non-null: slabs, row m of chunk c at ws + c * cstride + m * ld
+  long ld, cstride;
+  int chunks;
+  const float* rows;  // ws null: [batch rows][V]
+  float* store;       // ws non-null, optional: the summed rows are also left here [batch rows][V] (debug tap)
+  int rps;            // batch rows per slot
+  const uint8_t* cfg_on;
+  const float* fa;
+  const float* fb;
+};
+__device__ __forceinline__ f32x4 logit4(const LogitSrc& s, int row, int V, int j) {
+  if (s.ws) return slab_sum(s.ws + (long)row * s.ld + j, s.cstride, s.chunks);
+  return *reinterpret_cast<const f32x4*>(s.rows + (long)row * V + j);
+}
+
+__global__ void dep_argmax_kernel(LogitSrc src, int V, int k, int S, uint32_t* __restrict__ lat,
                                   uint32_t* __restrict__ last_tok, const uint8_t* __restrict__ run,
-                                  const uint8_t* __restrict__ forced, uint32_t pad, SampleArgs sa) {
+                                  const uint8_t* __restrict__ forced, uint32_t pad, SampleArgs sa, int lds_row_off) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int b = blockIdx.x;
   if (!run[b]) return;
+  float* logits = reinterpret_cast<float*>(smem + lds_row_off);  // the slot's row, staged once (V % 4 == 0)
+  const bool mix = src.rps == 2 && src.cfg_on[b];
+  if (src.ws || (V & 3) == 0) {
+    for (int j = 4 * (int)threadIdx.x; j < V; j += 4 * (int)blockDim.x) {
+      f32x4 o = logit4(src, b * src.rps, V, j);
+      if (src.ws && src.store) *reinterpret_cast<f32x4*>(src.store + (long)(b * src.rps) * V + j) = o;
+      if (mix) {  // cfg_mix_kernel: (l0 * a + 0) - (l1 * (a - 1) + 0)
+        const f32x4 l1 = logit4(src, b * src.rps + 1, V, j);
+        if (src.ws && src.store) *reinterpret_cast<f32x4*>(src.store + (long)(b * src.rps + 1) * V + j) = l1;
+        const float fa = src.fa[b], fb = src.fb[b];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float x = o[i] * fa + 0.0f, y = l1[i] * fb + 0.0f;
+          o[i] = x - y;
+        }
+      }
+      *reinterpret_cast<f32x4*>(logits + j) = o;
+    }
+  } else {  // finished rows of a width that is no multiple of four
+    for (int j = threadIdx.x; j < V; j += blockDim.x) {
+      float o = src.rows[(long)(b * src.rps) * V + j];
+      if (mix) {
+        const float x = o * src.fa[b] + 0.0f, y = src.rows[(long)(b * src.rps + 1) * V + j] * src.fb[b] + 0.0f;
+        o = x - y;
+      }
+      logits[j] = o;
+    }
+  }
+  __syncthreads();
   uint32_t tok;
   if (sa.top_k && sa.top_k[b] > 0)
-    tok = block_sample_topk(logits + (long)b * V, V, sa.top_k[b], sa.inv_t[b], sa.key + 8 * b, sa.pos + b, sa.vpad,
+    tok = block_sample_topk(logits, V, sa.top_k[b], sa.inv_t[b], sa.key + 8 * b, sa.pos + b, sa.vpad,
                             reinterpret_cast<uint64_t*>(smem), reinterpret_cast<float*>(smem + 8 * (size_t)sa.vpad));
   else
-    tok = (uint32_t)block_argmax_first(logits + (long)b * V, V);
+    tok = (uint32_t)block_argmax_first(logits, V);
   if (threadIdx.x == 0) {
     lat[(long)b * S + k] = tok;
     last_tok[b] = (forced[b] && k > 0) ? pad : tok;
