@@ -1565,7 +1565,7 @@ __global__ __launch_bounds__(256) void dep_head_kernel(float* __restrict__ x, fl
                                                        const float* __restrict__ nb, float eps, int rms) {
   __shared__ float red[8];
   const int b = blockIdx.x;
-  if (threadIdx.x == 0 && pos) {  // kv_builder_kernel, T = 1 (pos null: a rotary depformer runs the general builder instead)
+  if (threadIdx.x == 0) {  // kv_builder_kernel, T = 1
     const uint32_t p = pos[b], i = idx[b];
     start_pos[b] = p;
     widx[b] = i;  // active: (i + 0) % ctx = i (i < ctx); inactive: i

@@ -176,3 +176,13 @@ def test_tts_seeded_topk_sampling_matches_the_oracle(gpu, dsm, lib, orc, tts):
         for i in range(eng.step_idx(b)):
             assert np.array_equal(eng.audio_tokens(b, i), ora.audio_tokens(b, i))
     eng.close(); ora.close(); greedy.close()
+
+
+def test_tts_logits_rows_that_are_no_multiple_of_four_wide(gpu, dsm, lib, orc):
+    """The sampler stages a slot's logits row in LDS (r03): 16-byte accesses for the shipped vocabulary (2048), element by
+    element for a width like 34."""
+    from dsm_amd import synth
+    cfg = dsm.config_tts_tiny()
+    cfg.audio_vocab_size = 35  # 34 logits per slice
+    path = synth.make_synth_tts_weights(cfg, os.environ.get("DSM_WEIGHTS_DIR", "/tmp/dsm_weights"), tag="tts_tiny_vocab35")
+    _compare(dsm, orc, cfg, path, 3, 14, resets={6: [1]})
