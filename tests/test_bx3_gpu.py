@@ -5,7 +5,9 @@ tokens, VAD, AsrMsgs and every float tap bit for bit, like the mode-0 tests:
   * medium models with the real head dims: d_model 512 = two K-chunks (split-K slabs + the attention prologue's ordered reduce)
   * stt-1b-en_fr at the real dimensions, B = 3, against the oracle; B = 64 (two stream groups, MT = 2 tiles, 8-slab QKV) and
     B = 1024 (the whole-K loop form) by the slot-independence property against a B = 4 engine
-  * TTS (cross-attention, guidance, depformer with its K = 40 ... 2048 GEMMs and the load-time table fold) tiny + v202501 shapes"""
+  * TTS (cross-attention, guidance, depformer with its K = 40 ... 2048 GEMMs and the load-time table fold), tiny
+  * stt-2.6b-en and the v202501 TTS shapes in mode 1 ride on the tests that already build those checkpoints
+    (test_parity_full_gpu.py::test_stt_2_6b_en_shapes, test_tts_ca_gpu.py::test_cross_attention_and_guidance_at_v202501_shapes)"""
 import os
 
 import numpy as np
@@ -135,56 +137,3 @@ def test_tts_bx3(gpu, dsm, lib, orc):
         assert np.array_equal(te[act], to[act]) and np.array_equal(ae[act], ao[act]), f"tokens differ at step {s}"
     eng.close(); ora.close()
 
-
-def test_stt_2_6b_en_lm_step_bx3(gpu, dsm, lib, orc):
-    """BASELINE.json configs[2] in mode 1: one LM-only step of stt-2.6b-en (48 layers, 32 heads x 64, d_model 2048) at B = 34
-    — two stream groups of 32 + 2 slots: MT = 2 and MT = 1 bx3 tiles, hd-64 bf16 attention with the fused prologue."""
-    from dsm_amd import synth
-    cfg = dsm.config_stt_2_6b_en()
-    cfg.dot_mode = 1
-    lm, mimi = synth.make_synth_weights(cfg, WEIGHTS_DIR, tag="stt-2.6b-en")
-    try:
-        B = 34
-        rng = np.random.default_rng(9)
-        codes = rng.integers(0, cfg.mimi.quantizer_bins, (B, cfg.audio_codebooks)).astype(np.uint32)
-        mask = np.ones(B, dtype=np.uint8)
-        mask[5] = 0
-        act = mask.astype(bool)
-        eng = dsm.AsrEngine(cfg, B, lm, mimi)
-        et, _ = eng.step_tokens(codes, mask)
-        hid_e = eng.debug_read("lm.hidden", B * cfg.lm.d_model).reshape(B, -1)
-        lg_e = eng.debug_read("lm.logits", B * cfg.text_out_vocab_size).reshape(B, -1)
-        eng.close()
-        ora = orc.OracleAsr(cfg, B, lm, mimi)
-        ot, _ = ora.step_tokens(codes, mask)
-        hid_o = ora.debug_read("lm.hidden", B * cfg.lm.d_model).reshape(B, -1)
-        lg_o = ora.debug_read("lm.logits", B * cfg.text_out_vocab_size).reshape(B, -1)
-        ora.close()
-        assert np.array_equal(hid_e[act].view(np.uint32), hid_o[act].view(np.uint32)), "lm.hidden differs"
-        assert np.array_equal(lg_e[act].view(np.uint32), lg_o[act].view(np.uint32)), "logits differ"
-        assert np.array_equal(et[act], ot[act])
-    finally:
-        os.remove(lm)  # 5 GB
-
-
-def test_tts_v202501_shapes_with_cross_attention_bx3(gpu, dsm, lib, orc):
-    """The TTS step at the real dimensions in mode 1: 2048-d x 16 main LM with cross-attention in every layer and guidance,
-    depformer 1024-d x 4 x 32 slices (K = 1024 / 2048 / 2048-hidden bx3 GEMMs at 6 rows), a seeded top-k slot."""
-    from dsm_amd import synth
-    from test_tts_ca_gpu import _drive
-    cfg = dsm.config_tts_v202501()
-    cfg.dot_mode = 1
-    cfg.text_audio_delay_in_tokens, cfg.max_steps = 2, 64
-    cfg.cross_attention, cfg.ca_norm, cfg.ca_dim, cfg.ca_max_len, cfg.cfg_rows = 1, 0, 0, 128, 1
-    path = synth.make_synth_tts_weights(cfg, WEIGHTS_DIR, tag="tts-v202501-ca")
-    empty = synth.synth_ca_src(cfg, 125, 9)
-
-    def setup(x):
-        x.set_ca_src(0, synth.synth_ca_src(cfg, 125, 1), empty, 2.0)
-        x.set_ca_src(1, synth.synth_ca_src(cfg, 50, 2))
-        x.set_ca_src(2, synth.synth_ca_src(cfg, 128, 3), empty, 1.5)
-
-    try:
-        _drive(dsm, orc, cfg, path, 3, 5, setup, sampling={2: (50, 0.6, 7)})
-    finally:
-        os.remove(path)  # 1.1 GB

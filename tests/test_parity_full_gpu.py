@@ -164,6 +164,20 @@ def test_stt_2_6b_en_shapes(gpu, dsm, lib, orc):
     assert np.array_equal(hid_e[act].view(np.uint32), hid_o[act].view(np.uint32)), "B=34: lm.hidden differs"
     assert np.array_equal(lg_e[act].view(np.uint32), lg_o[act].view(np.uint32)), "B=34: logits differ"
     assert np.array_equal(et[act], ot[act])
+    # the same step in dot_mode 1 (r03): MT = 2 and MT = 1 bx3 tiles, hd-64 bf16 attention with the fused prologue
+    cfg1 = type(cfg).from_buffer_copy(cfg)
+    cfg1.dot_mode = 1
+    eng = dsm.AsrEngine(cfg1, B, lm, mimi)
+    et, _ = eng.step_tokens(codes, mask)
+    hid_e = eng.debug_read("lm.hidden", B * cfg.lm.d_model).reshape(B, -1)
+    eng.close()
+    ora = orc.OracleAsr(cfg1, B, lm, mimi)
+    ot, _ = ora.step_tokens(codes, mask)
+    hid_o1 = ora.debug_read("lm.hidden", B * cfg.lm.d_model).reshape(B, -1)
+    ora.close()
+    assert np.array_equal(hid_e[act].view(np.uint32), hid_o1[act].view(np.uint32)), "B=34, dot_mode 1: lm.hidden differs"
+    assert np.array_equal(et[act], ot[act])
+    assert not np.array_equal(hid_o1[act], hid_o[act])  # the two modes are different roundings of the same sums
     for p in (lm,):  # 5 GB: do not leave it in /tmp for the next test session
         os.remove(p)
 

@@ -111,6 +111,8 @@ def test_cross_attention_and_guidance_at_v202501_shapes(gpu, dsm, lib, orc):
         x.set_ca_src(2, synth.synth_ca_src(cfg, 128, 3), empty, 1.5)
 
     try:
-        _drive(dsm, orc, cfg, path, B, 7, setup, sampling={2: (50, 0.6, 7)})
+        _drive(dsm, orc, cfg, path, B, 5, setup, sampling={2: (50, 0.6, 7)})
+        cfg.dot_mode = 1  # the same model on the bf16 matrix instruction (r03): K = 1024 / 2048 / 5632 bx3 GEMMs at six rows
+        _drive(dsm, orc, cfg, path, B, 3, setup, sampling={2: (50, 0.6, 7)})
     finally:
         os.remove(path)  # 1.1 GB
