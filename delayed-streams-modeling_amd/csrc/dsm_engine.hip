@@ -216,6 +216,8 @@ struct dsm_engine {
   bool gate_occ3 = false;     // DSM_GATE_OCC3=1: the gate's whole-K kernel squeezed to 168 VGPRs (three waves per SIMD, 80 B of spills)
   int loop_depth = 4;         // DSM_LOOP_DEPTH=2: two-block rolling window (fewer registers, three waves per SIMD) where four is the default
   size_t attn_lds_pad = 60000;  // DSM_ATTN_LDS_PAD: extra dynamic LDS per attention workgroup of a large launch (2 per CU)
+  int bx3_nt2_min = 256;      // ... from this many workgroups on (DSM_BX3_NT2_MIN)
+  bool bx3_nt2 = true;        // DSM_BX3_NT2=0: one n-tile per wave in the whole-K bx3 kernel's plain-epilogue launches
   int dot_mode = 0;           // dsm_asr_config.dot_mode / dsm_tts_config.dot_mode: 1 = the bf16-weight GEMMs in "bx3" (gemm_bx3_kernel)
   int attn_nt = 1;            // DSM_ATTN_NT: ring-cache rows with non-temporal loads: 0 never, 1 bf16 rings (default), 2 every ring
   bool fuse_front = true;     // DSM_FUSE_FRONT=0: the SEANet front end as three GEMM launches (r01)
@@ -954,6 +956,16 @@ int launch_gemm_tiled(dsm_engine* e, hipStream_t st, GemmArgs& a) {
     a.ws = e->gemm_ws[wsid];
   }
   dim3 grid(gx, chunks, (a.M + 16 * MT - 1) / (16 * MT));
+  // dot_mode 1, whole-K form, plain epilogues: two n-tiles per wave (128 weight rows per workgroup).  With one n-tile a wave
+  // reads 12 LDS fragments (12 KB) per block for 12 MFMAs and the LDS, not the matrix pipe, bounds the loop; the gate has
+  // always run two.  DSM_BX3_NT2=0: one.
+  const bool nt2 = NT == 1 && e->dot_mode == 1 && sizeof(WT) == 2 && e->bx3_nt2 && a.chunk_loop > 1 && MT == 4 &&
+                   (EPI == EPI_STORE || EPI == EPI_QKV) && a.N % 128 == 0 && (long)(a.N / 128) * grid.z >= e->bx3_nt2_min;
+  if (nt2) {
+    grid.x = a.N / 128;
+    a.wg_cols = 128;
+    a.nt_stride = 64;
+  }
   a.ts = e->timeline ? e->dev_ts_slot(e->tag_gemm[e->sid(st)], e->sid(st), 1, 2) : nullptr;
   const int ph = e->prof_begin(e->tag_gemm[e->sid(st)], st);
   const bool bx3 = e->dot_mode == 1 && sizeof(WT) == 2;  // dot_mode 1: every bf16-weight GEMM on the bf16 matrix pipe
@@ -972,7 +984,9 @@ int launch_gemm_tiled(dsm_engine* e, hipStream_t st, GemmArgs& a) {
 #define DSM_LAUNCH_BX3(MTv)                                                                                     \
   if (a.chunk_loop > 1) hipLaunchKernelGGL((gemm_bx3_kernel<KVT, MTv, NT, EPI, true>), grid, dim3(256), pad, st, a); \
   else hipLaunchKernelGGL((gemm_bx3_kernel<KVT, MTv, NT, EPI, false>), grid, dim3(256), pad, st, a);
-  if (bx3 && EPI != EPI_RVQ) {
+  if (nt2) {
+    hipLaunchKernelGGL((gemm_bx3_kernel<KVT, 4, (NT == 1 ? 2 : NT), (EPI == EPI_GATE ? EPI_STORE : EPI), true>), grid, dim3(256), pad, st, a);
+  } else if (bx3 && EPI != EPI_RVQ) {
     if (MT == 4) { DSM_LAUNCH_BX3(4) } else if (MT == 2) { DSM_LAUNCH_BX3(2) } else { DSM_LAUNCH_BX3(1) }
   } else if (MT == 4) { DSM_LAUNCH_TILED(4) } else if (MT == 2) { DSM_LAUNCH_TILED(2) } else { DSM_LAUNCH_TILED(1) }
 #undef DSM_LAUNCH_BX3

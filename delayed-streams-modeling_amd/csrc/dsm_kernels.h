@@ -45,6 +45,8 @@ struct GemmArgs {
   const void* W;  // packed [Npad][Kpad], K zero-padded to a multiple of 32, rows to a multiple of 16
   int Kpad, K, N, M;
   int nt_stride;  // row distance between the NT n-tiles of one wave (16, or `hidden` for the gate)
+  int wg_cols;    // weight rows per workgroup (0 = 64).  128 with nt_stride 64: gemm_bx3_kernel's two-n-tile form for plain
+                  // epilogues — wave w owns columns 16w.. and 64 + 16w.. of the workgroup's 128
   // EPI_STORE
   const float* bias;   // [N] or null
   const float* scale;  // [N] or null (LayerScale)
@@ -752,7 +754,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bx3_kernel(GemmArgs a) {
   const int r = lane & 15, q = lane >> 4;
   const int chunks = LOOP ? 1 : (int)gridDim.y;
   const int m_base = blockIdx.z * (16 * MT);
-  const int n_base = blockIdx.x * 64 + 16 * wave;
+  const int n_base = blockIdx.x * (a.wg_cols ? a.wg_cols : 64) + 16 * wave;
   const uint16_t* W = reinterpret_cast<const uint16_t*>(a.W);
   const uint16_t* wrow[NT];
 #pragma unroll
