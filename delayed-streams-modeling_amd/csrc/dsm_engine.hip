@@ -225,6 +225,9 @@ struct dsm_engine {
   int smallk_min_tiles = 1024;  // DSM_SMALLK_MIN: from how many 64-row tiles on
   int smallk_mt = 4;          // DSM_SMALLK_MT: 16-row tiles per workgroup of those launches
   int chunk_loop_min_tiles = 384;  // DSM_CHUNK_LOOP_MIN (swept at B = 512 / 1024: 384 best)
+  bool bx3u = true;           // DSM_BX3U=0: split-K bx3 launches at M <= 32 keep r03's one-block look-ahead (gemm_bx3_kernel)
+  int wk_gate_max_chunks = 4; // DSM_WK_GATE_CHUNKS: gated-MLP input GEMMs with at most this many K-chunks run whole-K-in-the-workgroup
+                              // (gemm_wk_kernel: no slabs, no reduce launch); 0: never
   int prio_hi = 0;
   bool serialize_groups = false;  // dsm_debug_serialize_groups: every group on the model stream (profiling aid)
   hipEvent_t ev_codes_consumed = nullptr;
@@ -921,6 +924,22 @@ int launch_gemm_tiled(dsm_engine* e, hipStream_t st, GemmArgs& a) {
     a.defer_reduce = 0;
     chunks = 1;
   }
+  // r04: a gated-MLP input GEMM with a short reduction (the DepFormer's: K = 1024) keeps the whole K inside the workgroup —
+  // four waves, one chunk each, a (gate, up) tile pair x 16 rows per workgroup, the SiLU gate behind the ordered LDS sum:
+  // no slabs, no reduce launch.  experiments/gemm_wk_probe: 7.5 us against 13.4 (10.9 with gemm_bx3u_kernel) at M = 32; at
+  // K = 2048 the activation re-read (every workgroup reads 16 x K x 4 bytes from L2) makes it lose (27 against 20 us).
+  if (EPI == EPI_GATE && NT == 2 && sizeof(WT) == 2 && e->dot_mode == 1 && a.chunk_loop == 0 && chunks > 1 &&
+      chunks <= e->wk_gate_max_chunks && chunks <= 4 && a.M <= 64 && a.N % 16 == 0) {
+    auto ok4 = [](const RowMap& m) { return m.ld % 4 == 0 && m.bstride % 4 == 0; };
+    a.vec = (a.N % 4 == 0) && (!a.Y || ok4(a.ymap));
+    a.ts = e->timeline ? e->dev_ts_slot(e->tag_gemm[e->sid(st)], e->sid(st), 1, 2) : nullptr;
+    const int ph = e->prof_begin(e->tag_gemm[e->sid(st)], st);
+    hipLaunchKernelGGL((gemm_wk_kernel<KVT, 1, 2, EPI_GATE, 1, 4, 2, true, 4>), dim3(a.N / 16, 1, (a.M + 15) / 16), dim3(256),
+                       (size_t)chunks * 2 * 1024, st, a);
+    e->prof_end(ph, st);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   int MT = a.M > 32 ? 4 : (a.M > 16 ? 2 : 1);
   while (MT > 1 && (long)gx * chunks * ((a.M + 16 * MT - 1) / (16 * MT)) < 256) MT /= 2;  // cover the 256 CUs
   // one K-chunk and thousands of m-tiles (the first SEANet layers at large batches: K = 32..192, M = B x 1920): a
@@ -981,8 +1000,10 @@ int launch_gemm_tiled(dsm_engine* e, hipStream_t st, GemmArgs& a) {
   else if (roll && deep) hipLaunchKernelGGL((gemm_loop_kernel<WT, KVT, MTv, NT, EPI, DMAX>), grid, dim3(256), pad, st, a); \
   else if (roll) hipLaunchKernelGGL((gemm_loop_kernel<WT, KVT, MTv, NT, EPI, 2>), grid, dim3(256), pad, st, a);     \
   else hipLaunchKernelGGL((gemm_tile_kernel<WT, KVT, MTv, NT, EPI>), grid, dim3(256), pad, st, a);
+  // r04: the split-K form at M <= 32 issues every load of its chunk up front (gemm_bx3u_kernel, 48 KB of LDS at MT = 2)
 #define DSM_LAUNCH_BX3(MTv)                                                                                     \
   if (a.chunk_loop > 1) hipLaunchKernelGGL((gemm_bx3_kernel<KVT, MTv, NT, EPI, true>), grid, dim3(256), pad, st, a); \
+  else if (MTv <= 2 && e->bx3u && pad == 0) hipLaunchKernelGGL((gemm_bx3u_kernel<KVT, (MTv <= 2 ? MTv : 2), NT, EPI, 8>), grid, dim3(256), 0, st, a); \
   else hipLaunchKernelGGL((gemm_bx3_kernel<KVT, MTv, NT, EPI, false>), grid, dim3(256), pad, st, a);
   if (nt2) {
     hipLaunchKernelGGL((gemm_bx3_kernel<KVT, 4, (NT == 1 ? 2 : NT), (EPI == EPI_GATE ? EPI_STORE : EPI), true>), grid, dim3(256), pad, st, a);

@@ -45,6 +45,7 @@ struct GemmArgs {
   const void* W;  // packed [Npad][Kpad], K zero-padded to a multiple of 32, rows to a multiple of 16
   int Kpad, K, N, M;
   int nt_stride;  // row distance between the NT n-tiles of one wave (16, or `hidden` for the gate)
+  int w_ntiles;   // 16-row tiles of W in all (packed weight layouts, dsm_gemm_wk.h)
   int wg_cols;    // weight rows per workgroup (0 = 64).  128 with nt_stride 64: gemm_bx3_kernel's two-n-tile form for plain
                   // epilogues — wave w owns columns 16w.. and 64 + 16w.. of the workgroup's 128
   // EPI_STORE
@@ -912,6 +913,8 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(GemmArgs a, int chunks
     epi_store_qkv<KVT, EPI>(a, tot[0], m, n);
   launch_stamp_end(a.ts ? a.ts + 2 : nullptr);
 }
+
+#include "dsm_gemm_wk.h"  // whole-K-in-the-workgroup GEMM for M <= 64 (r04): no slabs, no reduce launch
 
 // Canonical row reduction (dsm_numerics.h): 256 threads per row, thread t owns elements 1024*it + 4*t + j;
 // wave butterflies, then the 4 wave totals left to right.  `red` = 8 floats of LDS.

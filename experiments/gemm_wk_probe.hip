@@ -1,0 +1,277 @@
+// gemm_wk_probe.hip — is a small-batch GEMM faster with the whole K inside the workgroup (gemm_wk_kernel, r04) than as split-K
+// workgroups + slabs + an ordered reduce launch (gemm_bx3_kernel + gemm_reduce*_kernel, r03)?
+//
+// Runs the PRODUCT kernels (dsm_kernels.h) on the LM / DepFormer shapes at M = 32 and 64, compares the two results bit for bit,
+// and times `reps` back-to-back launches of each form with HIP events; weights rotate through NBUF copies that are together
+// larger than the Infinity Cache, so every launch streams them from HBM as a real step does.  Under
+// `rocprofv3 --kernel-trace --stats` the same run gives the per-kernel durations.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I../delayed-streams-modeling_amd/csrc gemm_wk_probe.hip -o gemm_wk_probe
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+#define DSM_WK_STAMPS 1
+#include "dsm_kernels.h"
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP %s @%d\n", hipGetErrorString(e_), __LINE__); exit(2);} } while (0)
+
+static bool g_skip_wk = false;
+static RowMap plain_map(int M, int ld) { RowMap r; r.bstride = 0; r.rpb = M > 0 ? M : 1; r.ld = ld; r.toff = 0; return r; }
+
+struct Shape { const char* name; int N, K; int epi; };  // N: output width (gate: hidden)
+
+struct Bufs {
+  float *X, *res, *Yold, *Ynew, *ws, *norm_w, *xn_old, *xn_new;
+  std::vector<uint16_t*> W, Wt, Wc;
+};
+
+static GemmArgs make_args(const Shape& sh, const Bufs& b, int M, int buf, float* Y, float* xn) {
+  GemmArgs a;
+  memset(&a, 0, sizeof a);
+  a.X = b.X; a.xmap = plain_map(M, sh.K);
+  a.W = b.W[buf]; a.Kpad = sh.K; a.K = sh.K; a.M = M;
+  a.N = sh.N;
+  a.nt_stride = sh.epi == EPI_GATE ? sh.N : 16;
+  a.Y = Y; a.ymap = plain_map(M, sh.N);
+  a.vec = 1;
+  if (sh.epi == EPI_STORE) {
+    a.res = b.res; a.rmap = plain_map(M, sh.N);
+    a.norm_w = b.norm_w; a.norm_out = xn; a.norm_eps = 1e-8f; a.norm_rms = 1;
+  }
+  return a;
+}
+
+// r03 form: split-K workgroups + reduce launch (what launch_gemm_tiled does at M <= 64 in dot_mode 1)
+template <int EPI, int NT>
+static void launch_old(const Shape& sh, const Bufs& b, int M, int buf, hipStream_t st, bool bx3, int form = 0) {
+  GemmArgs a = form ? make_args(sh, b, M, buf, b.Ynew, b.xn_new) : make_args(sh, b, M, buf, b.Yold, b.xn_old);
+  if (a.N > 2048) a.norm_out = nullptr;
+  const int chunks = sh.K / 256, gx = (a.N + 63) / 64;
+  int MT = M > 32 ? 4 : (M > 16 ? 2 : 1);
+  a.ws_ntiles = (((NT - 1) * a.nt_stride) >> 4) + gx * 4;
+  a.ws = b.ws;
+  dim3 grid(gx, chunks, (M + 16 * MT - 1) / (16 * MT));
+  if (bx3 && form == 1) {
+    if (MT == 4) hipLaunchKernelGGL((gemm_bx3u_kernel<float, 4, NT, EPI, 4>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_bx3u_kernel<float, 2, NT, EPI, 8>), grid, dim3(256), 0, st, a);
+  } else if (bx3 && (form == 3 || form == 4)) {
+    a.W = form == 3 ? b.Wt[buf] : b.Wc[buf];
+    a.w_ntiles = (sh.N * (EPI == EPI_GATE ? 2 : 1)) / 16;
+    if (MT == 4) { if (form == 3) hipLaunchKernelGGL((gemm_bx3u_kernel<float, 4, NT, EPI, 4, 1>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((gemm_bx3u_kernel<float, 4, NT, EPI, 4, 2>), grid, dim3(256), 0, st, a); }
+    else { if (form == 3) hipLaunchKernelGGL((gemm_bx3u_kernel<float, 2, NT, EPI, 8, 1>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((gemm_bx3u_kernel<float, 2, NT, EPI, 8, 2>), grid, dim3(256), 0, st, a); }
+  } else if (bx3 && form == 2) {
+    if (MT == 4) hipLaunchKernelGGL((gemm_bx3u_kernel<float, 4, NT, EPI, 4>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_bx3u_kernel<float, 2, NT, EPI, 4>), grid, dim3(256), 0, st, a);
+  } else if (bx3) {
+    if (MT == 4) hipLaunchKernelGGL((gemm_bx3_kernel<float, 4, NT, EPI, false>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_bx3_kernel<float, 2, NT, EPI, false>), grid, dim3(256), 0, st, a);
+  } else {
+    if (MT == 4) hipLaunchKernelGGL((gemm_tile_kernel<uint16_t, float, 4, NT, EPI>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_tile_kernel<uint16_t, float, 2, NT, EPI>), grid, dim3(256), 0, st, a);
+  }
+  if (EPI == EPI_STORE && a.norm_out) {
+    if (a.N <= 1024) hipLaunchKernelGGL(gemm_reduce_rows_kernel<1>, dim3(M), dim3(256), 0, st, a, chunks);
+    else hipLaunchKernelGGL(gemm_reduce_rows_kernel<2>, dim3(M), dim3(512), 0, st, a, chunks);
+  } else {
+    const int out_tiles = ((M + 15) / 16) * ((a.N + 15) / 16);
+    hipLaunchKernelGGL((gemm_reduce_kernel<float, EPI>), dim3((out_tiles + 3) / 4), dim3(256), 0, st, a, chunks);
+  }
+}
+
+template <int EPI, int MT, int NT, int CPW, int NW, int OCC, bool BX3, int DX>
+static void launch_new(const Shape& sh, const Bufs& b, int M, int buf, hipStream_t st) {
+  GemmArgs a = make_args(sh, b, M, buf, b.Ynew, b.xn_new);
+  const int chunks = sh.K / 256;
+  const size_t lds = (size_t)chunks * NT * MT * 1024;
+  auto kern = gemm_wk_kernel<float, MT, NT, EPI, CPW, NW, OCC, BX3, DX>;
+  static bool attr = false;
+  if (!attr && lds > 64 * 1024) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); }
+  attr = true;
+  dim3 grid(EPI == EPI_GATE ? a.N / 16 : a.N / (16 * NT), 1, (M + 16 * MT - 1) / (16 * MT));
+  hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, a);
+  if (EPI == EPI_STORE)  // the norm stays a launch of its own in this form
+    hipLaunchKernelGGL(row_norm_kernel, dim3(M), dim3(256), 0, st, a.norm_out, a.Y, a.norm_w, (const float*)nullptr, M, a.N, a.norm_eps, a.norm_rms);
+}
+
+template <typename F>
+static double time_us(F&& f, int reps, int nbuf, hipStream_t st) {
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 4; ++i) f(i % nbuf);
+  CK(hipStreamSynchronize(st));
+  CK(hipEventRecord(e0, st));
+  for (int i = 0; i < reps; ++i) f(i % nbuf);
+  CK(hipEventRecord(e1, st));
+  CK(hipStreamSynchronize(st));
+  CK(hipGetLastError());
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+  return ms * 1000.0 / reps;
+}
+
+static size_t compare(const float* da, const float* db, size_t n) {
+  std::vector<uint32_t> a(n), b(n);
+  CK(hipMemcpy(a.data(), da, n * 4, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(b.data(), db, n * 4, hipMemcpyDeviceToHost));
+  size_t bad = 0;
+  for (size_t i = 0; i < n; ++i) bad += a[i] != b[i];
+  return bad;
+}
+
+#define VARIANT(EPI, MT, NT, CPW, NW, OCC, BX3, DX)                                                                      \
+  do {                                                                                                                   \
+    if ((sh.K / 256 + CPW - 1) / CPW > NW) break;                                                                        \
+    CK(hipMemset(b.Ynew, 0xFF, (size_t)M * sh.N * 4));                                                                   \
+    launch_new<EPI, MT, NT, CPW, NW, OCC, BX3, DX>(sh, b, M, 0, st);                                                     \
+    CK(hipStreamSynchronize(st)); CK(hipGetLastError());                                                                 \
+    const size_t bad = compare(b.Yold, b.Ynew, (size_t)M * sh.N) + ((EPI == EPI_STORE && sh.N <= 2048) ? compare(b.xn_old, b.xn_new, (size_t)M * sh.N) : 0); \
+    const double t = time_us([&](int buf) { launch_new<EPI, MT, NT, CPW, NW, OCC, BX3, DX>(sh, b, M, buf, st); }, reps, NBUF, st); \
+    printf("  wk  MT=%d NT=%d CPW=%d NW=%2d OCC=%d DX=%d : %7.2f us  mismatches %zu\n", MT, NT, CPW, NW, OCC, DX, t, bad); \
+  } while (0)
+
+template <bool BX3>
+static void run_shape(const Shape& sh, int M, hipStream_t st) {
+  const int NBUF = (int)(400e6 / ((double)sh.N * (sh.epi == EPI_GATE ? 2 : 1) * sh.K * 2)) + 2, reps = 200;
+  Bufs b;
+  const size_t wn = (size_t)sh.N * (sh.epi == EPI_GATE ? 2 : 1) * sh.K;
+  std::vector<float> hx((size_t)M * sh.K), hr((size_t)M * sh.N), hn(sh.N);
+  for (size_t i = 0; i < hx.size(); ++i) hx[i] = (float)((i * 2654435761u) % 20011) / 10000.f - 1.f;
+  for (size_t i = 0; i < hr.size(); ++i) hr[i] = (float)((i * 40503u) % 1999) / 1000.f - 1.f;
+  for (size_t i = 0; i < hn.size(); ++i) hn[i] = 0.5f + (float)(i % 17) / 16.f;
+  std::vector<uint16_t> hw(wn);
+  for (size_t i = 0; i < wn; ++i) hw[i] = (uint16_t)(((i * 40503u) & 0x8000u) | 0x3A00u | ((i * 2654435761u >> 7) & 0x3FF));
+  CK(hipMalloc(&b.X, hx.size() * 4)); CK(hipMemcpy(b.X, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMalloc(&b.res, hr.size() * 4)); CK(hipMemcpy(b.res, hr.data(), hr.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMalloc(&b.norm_w, hn.size() * 4)); CK(hipMemcpy(b.norm_w, hn.data(), hn.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMalloc(&b.Yold, hr.size() * 4)); CK(hipMalloc(&b.Ynew, hr.size() * 4));
+  CK(hipMalloc(&b.xn_old, hr.size() * 4)); CK(hipMalloc(&b.xn_new, hr.size() * 4));
+  CK(hipMalloc(&b.ws, (size_t)(sh.K / 256) * 64 * (sh.N * 2 + 64) * 4));
+  b.W.resize(NBUF); b.Wt.resize(NBUF); b.Wc.resize(NBUF);
+  {
+    const size_t rows = wn / sh.K, nblk = sh.K / 32, ntiles = rows / 16;
+    std::vector<uint16_t> ht(wn), hc(wn);
+    for (size_t n = 0; n < rows; ++n)
+      for (size_t k = 0; k < (size_t)sh.K; ++k) {
+        const size_t lane = ((k % 32) / 8) * 16 + (n % 16), v = hw[n * sh.K + k];
+        ht[(((n / 16) * nblk + k / 32) * 64 + lane) * 8 + k % 8] = (uint16_t)v;
+        hc[((((k / 256) * ntiles + n / 16) * 8 + (k % 256) / 32) * 64 + lane) * 8 + k % 8] = (uint16_t)v;
+      }
+    for (int i = 0; i < NBUF; ++i) {
+      CK(hipMalloc(&b.W[i], wn * 2)); CK(hipMemcpy(b.W[i], hw.data(), wn * 2, hipMemcpyHostToDevice));
+      CK(hipMalloc(&b.Wt[i], wn * 2)); CK(hipMemcpy(b.Wt[i], ht.data(), wn * 2, hipMemcpyHostToDevice));
+      CK(hipMalloc(&b.Wc[i], wn * 2)); CK(hipMemcpy(b.Wc[i], hc.data(), wn * 2, hipMemcpyHostToDevice));
+    }
+  }
+  CK(hipDeviceSynchronize());
+  printf("%s N=%d K=%d M=%d %s  (%.1f MB of weights, %d copies)\n", sh.name, sh.N, sh.K, M, BX3 ? "dot_mode 1" : "dot_mode 0", wn * 2 / 1e6, NBUF);
+  auto oldf = [&](int buf, int form) {
+    if (sh.epi == EPI_GATE) launch_old<EPI_GATE, 2>(sh, b, M, buf, st, BX3, form); else launch_old<EPI_STORE, 1>(sh, b, M, buf, st, BX3, form);
+  };
+  auto old = [&](int buf) { oldf(buf, 0); };
+  const double told = time_us(old, reps, NBUF, st);
+  old(0);
+  CK(hipStreamSynchronize(st));
+  if (BX3) for (int form = 1; form <= 4; ++form) {
+    CK(hipMemset(b.Ynew, 0xFF, (size_t)M * sh.N * 4));
+    oldf(0, form);
+    CK(hipStreamSynchronize(st)); CK(hipGetLastError());
+    const size_t bad = compare(b.Yold, b.Ynew, (size_t)M * sh.N);
+    const double t = time_us([&](int buf) { oldf(buf, form); }, reps, NBUF, st);
+    printf("  bx3u form %d (1: HB 8|4, 2: HB 4, 3: tile-major W, 4: chunk-major W) + reduce : %7.2f us  mismatches %zu\n", form, t, bad);
+  }
+  if (g_skip_wk) printf("  (wk variants skipped)\n");
+  printf("  old split-K + reduce%s            : %7.2f us\n", sh.epi == EPI_STORE ? "+norm" : "     ", told);
+  if (g_skip_wk) {
+  } else if (sh.epi == EPI_GATE) {
+    if (M <= 32) {
+      VARIANT(EPI_GATE, 2, 2, 1, 8, 2, BX3, 2); VARIANT(EPI_GATE, 2, 2, 1, 8, 1, BX3, 4); VARIANT(EPI_GATE, 2, 2, 1, 4, 2, BX3, 2);
+      VARIANT(EPI_GATE, 2, 2, 2, 4, 2, BX3, 2); VARIANT(EPI_GATE, 1, 2, 1, 8, 2, BX3, 2); VARIANT(EPI_GATE, 1, 2, 1, 8, 2, BX3, 4);
+    } else {
+      VARIANT(EPI_GATE, 4, 2, 1, 8, 1, BX3, 2); VARIANT(EPI_GATE, 2, 2, 1, 8, 2, BX3, 2); VARIANT(EPI_GATE, 2, 2, 1, 8, 1, BX3, 4);
+      VARIANT(EPI_GATE, 4, 2, 1, 4, 1, BX3, 2); VARIANT(EPI_GATE, 2, 2, 1, 4, 2, BX3, 2); VARIANT(EPI_GATE, 1, 2, 1, 8, 2, BX3, 4);
+    }
+  } else {
+    if (M <= 32) {
+      VARIANT(EPI_STORE, 2, 1, 1, 8, 2, BX3, 2); VARIANT(EPI_STORE, 2, 1, 1, 8, 2, BX3, 4); VARIANT(EPI_STORE, 2, 2, 1, 8, 2, BX3, 2);
+      VARIANT(EPI_STORE, 1, 1, 1, 8, 2, BX3, 4); VARIANT(EPI_STORE, 1, 2, 1, 8, 2, BX3, 4);
+      VARIANT(EPI_STORE, 2, 1, 1, 4, 2, BX3, 2); VARIANT(EPI_STORE, 2, 1, 2, 4, 2, BX3, 2); VARIANT(EPI_STORE, 1, 1, 1, 4, 2, BX3, 4);
+      VARIANT(EPI_STORE, 2, 1, 2, 11, 1, BX3, 2); VARIANT(EPI_STORE, 2, 1, 3, 8, 1, BX3, 2); VARIANT(EPI_STORE, 1, 1, 2, 11, 1, BX3, 4);
+    } else {
+      VARIANT(EPI_STORE, 4, 1, 1, 8, 2, BX3, 2); VARIANT(EPI_STORE, 2, 1, 1, 8, 2, BX3, 2); VARIANT(EPI_STORE, 2, 1, 1, 8, 2, BX3, 4);
+      VARIANT(EPI_STORE, 4, 2, 1, 8, 1, BX3, 2); VARIANT(EPI_STORE, 2, 2, 1, 8, 2, BX3, 2); VARIANT(EPI_STORE, 1, 1, 1, 8, 2, BX3, 4);
+      VARIANT(EPI_STORE, 4, 1, 1, 4, 2, BX3, 2); VARIANT(EPI_STORE, 2, 1, 1, 4, 2, BX3, 2);
+      VARIANT(EPI_STORE, 4, 1, 2, 11, 1, BX3, 2); VARIANT(EPI_STORE, 2, 1, 2, 11, 1, BX3, 2); VARIANT(EPI_STORE, 1, 1, 2, 11, 1, BX3, 4);
+    }
+  }
+  for (int i = 0; i < NBUF; ++i) { CK(hipFree(b.W[i])); CK(hipFree(b.Wt[i])); CK(hipFree(b.Wc[i])); }
+  CK(hipFree(b.X)); CK(hipFree(b.res)); CK(hipFree(b.norm_w)); CK(hipFree(b.Yold)); CK(hipFree(b.Ynew));
+  CK(hipFree(b.xn_old)); CK(hipFree(b.xn_new)); CK(hipFree(b.ws));
+}
+
+// per-workgroup phase stamps of one gemm_bx3u_kernel launch (cold weights): start, X staged, first W block in, last W block
+// in, MFMAs done, slab stored — relative to the first workgroup's start, as percentiles over the grid
+template <int EPI, int NT>
+static void stamps(const Shape& sh, int M, hipStream_t st) {
+  Bufs b;
+  const size_t wn = (size_t)sh.N * (sh.epi == EPI_GATE ? 2 : 1) * sh.K;
+  CK(hipMalloc(&b.X, (size_t)M * sh.K * 4)); CK(hipMemset(b.X, 0, (size_t)M * sh.K * 4));
+  CK(hipMalloc(&b.Ynew, (size_t)M * sh.N * 8)); CK(hipMalloc(&b.xn_new, (size_t)M * sh.N * 8));
+  CK(hipMalloc(&b.ws, (size_t)(sh.K / 256) * 64 * (sh.N * 2 + 64) * 4));
+  b.W.resize(8);
+  for (int i = 0; i < 8; ++i) { CK(hipMalloc(&b.W[i], wn * 2)); CK(hipMemset(b.W[i], 0x3c, wn * 2)); }
+  b.res = b.norm_w = b.Yold = b.xn_old = nullptr;
+  const int chunks = sh.K / 256, gx = (sh.N + 63) / 64, nwg = gx * chunks;
+  unsigned long long* ts;
+  CK(hipMalloc(&ts, (16 + 8 * (size_t)nwg) * 8));
+  std::vector<unsigned long long> h(16 + 8 * (size_t)nwg);
+  for (int rep = 0; rep < 3; ++rep) {
+    for (int i = 0; i < 8; ++i) {  // sweep the copies so that the timed one (i == 7 -> buffer rep) comes from HBM
+      GemmArgs a = make_args(sh, b, M, i, b.Ynew, b.xn_new);
+      a.res = nullptr; a.norm_out = nullptr;
+      a.ws_ntiles = (((NT - 1) * a.nt_stride) >> 4) + gx * 4; a.ws = b.ws;
+      if (i == 7) { CK(hipMemsetAsync(ts, 0xFF, 16, st)); CK(hipMemsetAsync(ts + 1, 0, 8, st)); a.ts = ts; }
+      hipLaunchKernelGGL((gemm_bx3u_kernel<float, 2, NT, EPI, 8>), dim3(gx, chunks, 1), dim3(256), 0, st, a);
+    }
+    CK(hipStreamSynchronize(st));
+  }
+  CK(hipMemcpy(h.data(), ts, h.size() * 8, hipMemcpyDeviceToHost));
+  unsigned long long t0 = ~0ull;
+  for (int w = 0; w < nwg; ++w) t0 = std::min(t0, h[16 + 8 * w + 6]);
+  printf("%s M=%d grid %dx%d: per-workgroup stamps, us after the first workgroup's start (p10 / p50 / p90 / max)\n", sh.name, M, gx, chunks);
+  const char* names[7] = {"loads issued", "X staged", "first W block in", "last W block in", "MFMAs done", "slab stored", "entered"};
+  for (int kk = 0; kk < 7; ++kk) {
+    const int k = (kk + 6) % 7;
+    std::vector<double> v(nwg);
+    for (int w = 0; w < nwg; ++w) v[w] = (double)(h[16 + 8 * w + k] - t0) / 100.0;
+    std::sort(v.begin(), v.end());
+    printf("  %-22s %6.2f %6.2f %6.2f %6.2f\n", names[k], v[nwg / 10], v[nwg / 2], v[nwg * 9 / 10], v[nwg - 1]);
+  }
+  for (int i = 0; i < 8; ++i) CK(hipFree(b.W[i]));
+  CK(hipFree(b.X)); CK(hipFree(b.Ynew)); CK(hipFree(b.xn_new)); CK(hipFree(b.ws)); CK(hipFree(ts));
+}
+
+int main(int argc, char** argv) {
+  const Shape shapes[] = {
+      {"lm_qkv", 6144, 2048, EPI_STORE}, {"lm_out_proj", 2048, 2048, EPI_STORE}, {"lm_gate", 5632, 2048, EPI_GATE},
+      {"lm_ff_out", 2048, 5632, EPI_STORE}, {"dep_qkv", 3072, 1024, EPI_STORE}, {"dep_out_proj", 1024, 1024, EPI_STORE},
+      {"dep_gate", 2048, 1024, EPI_GATE}, {"dep_ff_out", 1024, 2048, EPI_STORE}};
+  const int mode = argc > 1 ? atoi(argv[1]) : 1;
+  hipStream_t st;
+  CK(hipStreamCreate(&st));
+  if (mode == 3) g_skip_wk = true;
+  if (mode == 2) {
+    stamps<EPI_STORE, 1>(shapes[0], 32, st); stamps<EPI_STORE, 1>(shapes[1], 32, st);
+    stamps<EPI_GATE, 2>(shapes[2], 32, st); stamps<EPI_STORE, 1>(shapes[3], 32, st);
+    stamps<EPI_GATE, 2>(shapes[6], 32, st);
+    return 0;
+  }
+  for (const Shape& sh : shapes)
+    for (int M : {32, 64}) {
+      if (mode == 1 || mode == 3) run_shape<true>(sh, M, st); else run_shape<false>(sh, M, st);
+      fflush(stdout);
+    }
+  return 0;
+}
