@@ -62,7 +62,46 @@ def parse():
     ap.add_argument("--spawn-check", action="store_true",
                     help="CPU rehearsal of the multi-rank control path (gloo): no engine, no GPU")
     ap.add_argument("--weights-dir", default=os.environ.get("DSM_WEIGHTS_DIR", "/tmp/dsm_weights"))
+    ap.add_argument("--other-configs", default="stt-2.6b-en:128,tts:32",
+                    help="the other single-GPU BASELINE.json configurations, run as short legs after the headline (N = 1, stt-1b-en_fr at "
+                         "B = 64 only) and reported under `other_configs`: `<config>:<batch>` with config stt-2.6b-en or tts; '' to skip")
+    ap.add_argument("--no-agreement", action="store_true", help="skip the dot_mode 1 vs dot_mode 0 agreement pass (`dot_mode_agreement`)")
+    ap.add_argument("--tts-guided-leg", type=int, default=1, help="--workload tts: also time the cfg_rows = 1 engine (two batch rows per slot, guidance on)")
     return ap.parse_args()
+
+
+def other_config_leg(args, spec):
+    """One of the other BASELINE.json configurations as a child `bench.py` run on the same GPU (its own engine and a synthetic
+    checkpoint in a scratch directory that is deleted afterwards); returns the fields VERDICT r03 #4 asks for."""
+    import shutil
+    import tempfile
+    name, batch = spec.split(":")
+    wd = tempfile.mkdtemp(prefix="dsm_other_", dir=os.path.dirname(args.weights_dir.rstrip("/")) or "/tmp")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--batch", batch, "--steps", "30", "--warmup", "5", "--no-cpu-baseline",
+           "--capacity-legs", "", "--host-path-legs", "", "--other-configs", "", "--no-agreement", "--dot-mode", str(args.dot_mode), "--weights-dir", wd]
+    cmd += ["--workload", "tts"] if name == "tts" else ["--config", name, "--fast-fill"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": (r.stderr or r.stdout)[-300:]}
+        j = json.loads(lines[-1])
+        out = {"metric": j["metric"], "ms_per_step": j["ms_per_step"], "rtf": j["rtf"], "value": j["value"], "dot_mode": j.get("dot_mode"),
+               "workload": j["config"]["workload"],
+               "roofline": {k: j["roofline"].get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_us", "algorithmic_bytes_per_launch")}}
+        if "isolated_single_stream" in j["roofline"]:
+            out["roofline"]["isolated_frac"] = j["roofline"]["isolated_single_stream"]["frac"]
+        if "whole_step" in j:
+            out["whole_step_frac_of_hbm_peak"] = j["whole_step"]["frac_of_hbm_peak"]
+        for k in ("guided_leg", "pipelined"):
+            if k in j:
+                out[k] = j[k]
+        out["how"] = "child run of bench.py on the same GPU after the headline: 30 timed steps" + ("" if name == "tts" else ", ring positions jumped to the wrapped steady state (--fast-fill)")
+        return out
+    except Exception as ex:
+        return {"error": str(ex)[:300]}
+    finally:
+        shutil.rmtree(wd, ignore_errors=True)
 
 
 def cpu_baseline(cfg, B, lm_path, mimi_path, n_steps):
@@ -91,7 +130,7 @@ def cpu_baseline(cfg, B, lm_path, mimi_path, n_steps):
     o.close()
     cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
     return {"value": B * 0.08 / dt, "unit": "x realtime (stream-seconds of audio per wall second)",
-            "cores": cores, "kind": "port",
+            "cores": cores, "kind": "port", "dot_mode": 0,
             "sample": f"{n_steps} frame(s) x {B} streams on full rings ({cfg.lm.context} LM / {cfg.mimi.transformer.context} Mimi frames, "
                       f"the steady state the GPU line is timed in), {dt * 1000:.0f} ms/step, oracle load {load_s:.0f} s; "
                       "dot_mode 0 (f32 fma dot products); Candle itself cannot be built offline"}
@@ -136,39 +175,59 @@ def bench_tts(args, world, rank, local_rank):
     import torch
     import dsm_amd
     from dsm_amd import synth
-    cfg = dsm_amd.config_tts_v202501()
+    cfg = dsm_amd.config_tts_v202501()  # cross-attention in every main-LM layer, as the reference's tts_202501 (core/lm.rs:392-396)
     cfg.dot_mode = args.dot_mode
     B = args.batch
-    path = synth.make_synth_tts_weights(cfg, args.weights_dir, tag="tts-v202501" + ("" if world == 1 else f".rank{rank}"))
-    eng = dsm_amd.TtsEngine(cfg, B, path, device_id=local_rank)
-    if world > 1:
-        os.remove(path)
+    path = synth.make_synth_tts_weights(cfg, args.weights_dir, tag="tts-v202501-ca" + ("" if world == 1 else f".rank{rank}"))
     rng = np.random.default_rng(3 + rank)
     mask = np.ones(B, dtype=np.uint8)
     fill = cfg.text_audio_delay_in_tokens + cfg.acoustic_delay + 3  # past both delay windows: every codebook feeds back
+    SRC_ROWS = 125  # speaker_cond_n_speakers (5) x 2 s at 12.5 Hz: what the server's conditioner hands State::new (srv/tts.rs:426-441)
 
-    def step():
-        prev = rng.integers(4, cfg.text_in_vocab_size - 1, B).astype(np.uint32)
-        allowed = rng.integers(4, cfg.text_in_vocab_size - 1, B).astype(np.int32)
-        eng.step(prev, allowed, mask)
+    def run(c, guided, steps, warmup):
+        eng = dsm_amd.TtsEngine(c, B, path, device_id=local_rank)
+        empty = synth.synth_ca_src(c, SRC_ROWS, 9)
+        for b in range(B):  # the branch the server runs: every generation has a conditioning source
+            if guided:
+                eng.set_ca_src(b, synth.synth_ca_src(c, SRC_ROWS, 100 + b), empty, 2.0)
+            else:
+                eng.set_ca_src(b, synth.synth_ca_src(c, SRC_ROWS, 100 + b))
 
-    for _ in range(fill + args.warmup):
-        step()
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=torch.device("cuda", local_rank))
-    if world > 1:
-        dist.barrier()
-        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-    ms = float(dt.item()) / args.steps * 1000
-    if rank == 0:
+        def step():
+            prev = rng.integers(4, c.text_in_vocab_size - 1, B).astype(np.uint32)
+            allowed = rng.integers(4, c.text_in_vocab_size - 1, B).astype(np.int32)
+            eng.step(prev, allowed, mask)
+
+        for _ in range(fill + warmup):
+            step()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        if world > 1:
+            dist.barrier()
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         m = eng.metrics()
+        eng.close()
+        return float(dt.item()) / steps * 1000, m
+
+    ms, m = run(cfg, False, args.steps, args.warmup)
+    guided = None
+    if args.tts_guided_leg and world == 1:
+        gcfg = type(cfg).from_buffer_copy(cfg)
+        gcfg.cfg_rows = 1
+        gms, _ = run(gcfg, True, min(args.steps, 20), 3)
+        guided = {"ms_per_step": gms, "rtf": 80.0 / gms, "batch_rows": 2 * B,
+                  "what": "cfg_rows = 1: every slot runs a conditional and an unconditional row, logits mixed l0 * a - l1 * (a - 1) "
+                          "(core/tts_streaming.rs:164-173,207-214), alpha 2.0 on every slot"}
+    if world > 1:
+        os.remove(path)
+    if rank == 0:
         wbytes = m.algorithmic_bytes_lm
         achieved = wbytes / (ms * 1e-3) / 1e9
         print(json.dumps({"metric": "TTS step real-time generation throughput @ bs=%d" % B, "value": world * B * 0.08 / (ms / 1000),
@@ -177,8 +236,9 @@ def bench_tts(args, world, rank, local_rank):
                           "dtype": ("bf16 weights, f32 activations as three exact bf16 pieces, f32 accumulate" if args.dot_mode == 1
                                     else "bf16 weights, f32 activations/accumulate"),
                           "data": "synthetic", "rtf": 80.0 / ms, "dot_mode": args.dot_mode,
-                          "config": {"workload": "tts v202501 State::step (2048-d x 16 LM + 32-slice depformer, greedy), batch=%d, "
-                                                 "KV fill %d frames" % (B, fill + args.warmup)},
+                          "config": {"workload": "tts v202501 State::step (2048-d x 16 LM with cross-attention to a %d-row source per slot + "
+                                                 "32-slice depformer, greedy), batch=%d, KV fill %d frames" % (SRC_ROWS, B, fill + args.warmup)},
+                          "guided_leg": guided,
                           # the step is one dependent chain of ~1400 launches of 4-7 us (profiles/r03/tts_kernel_trace_summary.txt):
                           # no kernel dominates, so the roofline object prices the WHOLE step against the bytes it has to stream
                           "roofline": {"bound": "hbm", "kernel": "whole step (launch-bound chain: 16 LM layers + 32 depformer slices x 4 layers, "
@@ -191,7 +251,6 @@ def bench_tts(args, world, rank, local_rank):
                                        "traffic": None},
                           "graphs": {"graph_launches": int(m.graph_launches), "eager_bodies": int(m.eager_bodies),
                                      "capture_failures": int(m.capture_failures)}}))
-    eng.close()
 
 
 def spawn_ranks(args):
@@ -465,6 +524,21 @@ def main():
             except Exception as ex:
                 host_legs[Bl] = {"error": str(ex)[:200]}
 
+    # dot_mode 1 against dot_mode 0 on this build, these weights, full rings (delayed-streams-modeling_amd/agreement.py)
+    agree = None
+    if world == 1 and args.config == "stt-1b-en_fr" and args.part == "all" and not args.no_overlap and not args.no_agreement:
+        try:
+            from dsm_amd import agreement
+            agree = agreement.asr_agreement(dsm_amd, cfg, 8, lm_path, mimi_path, arena=eng.weight_arena(), steps=30, device_id=local_rank)
+            agree.pop("flips", None)
+        except Exception as ex:
+            agree = {"error": str(ex)[:200]}
+        torch.cuda.empty_cache()
+    others = {}
+    if world == 1 and args.config == "stt-1b-en_fr" and B == 64 and args.part == "all" and not args.no_overlap and args.other_configs:
+        for spec in [x for x in args.other_configs.split(",") if x]:
+            others[spec] = other_config_leg(args, spec)
+
     if rank == 0:
         H, hd, L = cfg.lm.num_heads, cfg.lm.d_model // cfg.lm.num_heads, cfg.lm.num_layers
         kv_b = 2 if cfg.kv_bf16 else 4
@@ -482,7 +556,7 @@ def main():
         # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (bench.py cannot run under --pmc and
         # time itself): 2 x FETCH_SIZE (gfx950 counts 64 B per 128-B request) + WRITE_SIZE, per dispatch
         traffic, traffic_src = None, None
-        for rnd in ("r03", "r02", "r01"):
+        for rnd in ("r04", "r03", "r02", "r01"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", rnd, "pmc_hbm_traffic.json")))
                 for k in pmc["kernels"]:
@@ -561,6 +635,10 @@ def main():
                             "dsm_worker_step_encode (pre_process, pinned staging, H2D, Mimi encode; run-ahead) || dsm_worker_step_model "
                             "(LM step, post_process, OutMsg::Step per channel) -> dsm_worker_recv; free-running, rtf = 80 ms / ms_per_frame",
                     "streams_at_rtf_ge_1p10_device_and_host": max(safe) if safe else None}
+        if agree is not None:
+            out["dot_mode_agreement"] = agree
+        if others:
+            out["other_configs"] = others
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, B, lm_path, mimi_path, args.cpu_steps)
         print(json.dumps(out))

@@ -120,7 +120,7 @@ ABI_SYMBOLS = [
     "dsm_asr_step_pcm", "dsm_asr_poll_msgs", "dsm_asr_reset_slot", "dsm_mimi_reset_slot", "dsm_sync",
     "dsm_get_metrics", "dsm_batch_size", "dsm_n_q", "dsm_mimi_encode_step_dev", "dsm_asr_step_tokens_dev",
     "dsm_streams_join", "dsm_debug_read", "dsm_asr_step_pcm_dev", "dsm_prof_enable", "dsm_prof_read",
-    "dsm_debug_set_positions", "dsm_mimi_decode_step", "dsm_mimi_decode_step_dev",
+    "dsm_debug_set_positions", "dsm_debug_set_text_tokens", "dsm_mimi_decode_step", "dsm_mimi_decode_step_dev",
     "dsm_lm_stream_groups", "dsm_debug_serialize_groups", "dsm_prof_read_device", "dsm_prof_timeline", "dsm_prof_timeline_read",
     "dsm_wav_decode", "dsm_free", "dsm_linear_resampler_new", "dsm_linear_resampler_process",
     "dsm_linear_resampler_free", "dsm_ogg_demux_new", "dsm_ogg_demux_free", "dsm_ogg_demux_push", "dsm_ogg_demux_next",
@@ -182,6 +182,8 @@ def load_library(path=None):
     lib.dsm_mimi_decode_step_dev.restype = C.c_int
     lib.dsm_debug_set_positions.argtypes = [vp, C.c_uint32, C.c_uint32]
     lib.dsm_debug_set_positions.restype = C.c_int
+    lib.dsm_debug_set_text_tokens.argtypes = [vp, vp]
+    lib.dsm_debug_set_text_tokens.restype = C.c_int
     lib.dsm_prof_enable.argtypes = [vp, C.c_uint]
     lib.dsm_prof_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     for name in ("dsm_mimi_encode_step", "dsm_asr_step_tokens", "dsm_asr_step_pcm", "dsm_asr_poll_msgs",
@@ -699,6 +701,12 @@ class AsrEngine:
 
     def debug_set_positions(self, lm_pos, mimi_pos):
         self._check(self.lib.dsm_debug_set_positions(self.h, lm_pos, mimi_pos))
+
+    def debug_set_text_tokens(self, tokens):
+        """Teacher forcing: the text token every slot feeds back into its next step."""
+        t = np.ascontiguousarray(tokens, dtype=np.uint32)
+        assert t.shape == (self.B,)
+        self._check(self.lib.dsm_debug_set_text_tokens(self.h, t.ctypes.data))
 
     def prof_read_device(self):
         """Like prof_read, from the in-kernel device-clock brackets (attention classes only)."""

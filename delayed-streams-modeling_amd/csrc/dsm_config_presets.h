@@ -95,5 +95,10 @@ static inline void dsm_preset_tts_v202501(dsm_tts_config* c) {
   c->acoustic_delay = 2; c->text_eop_token = 0; c->text_bos_token = 1; c->text_eos_token = 2; c->text_pad_token = 3;
   c->text_start_token = 8000; c->text_audio_delay_in_tokens = 25; c->max_consecutive_pads = 10; c->max_steps = 4096;
   c->kv_bf16 = 1;
+  /* core/lm.rs:392-396 tts_202501: cross_attention = Some((CrossAttentionGating::Normal, NormType::LayerNorm, None)), and the
+   * server always builds its State with Some(CaSrc::Tokens(..)) (srv/tts.rs:426-441): the preset carries the branch the
+   * reference runs.  Sources: speaker_cond_n_speakers = 5 x 25 rows at 12.5 Hz -> 125 rows; 128 fit.  Guidance
+   * (two batch rows per slot, cfg_alpha) stays opt-in through cfg_rows, as it is per request in the reference. */
+  c->cross_attention = 1; c->ca_norm = 0; c->ca_dim = 0; c->ca_max_len = 128; c->cfg_rows = 0;
 }
 #endif

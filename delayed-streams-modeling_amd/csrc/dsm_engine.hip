@@ -226,6 +226,8 @@ struct dsm_engine {
   int smallk_mt = 4;          // DSM_SMALLK_MT: 16-row tiles per workgroup of those launches
   int chunk_loop_min_tiles = 384;  // DSM_CHUNK_LOOP_MIN (swept at B = 512 / 1024: 384 best)
   bool bx3u = true;           // DSM_BX3U=0: split-K bx3 launches at M <= 32 keep r03's one-block look-ahead (gemm_bx3_kernel)
+  bool wk_norm = false;       // DSM_WK_NORM=1: where the MLP input GEMM runs whole-K, norm2 moves into its prologue (gemm_wkn_kernel) and out_proj
+                              // stores the residual stream itself (two launches fewer per layer; measured 6.56 against 6.45 ms per TTS step: off)
   int wk_gate_max_chunks = 4; // DSM_WK_GATE_CHUNKS: gated-MLP input GEMMs with at most this many K-chunks run whole-K-in-the-workgroup
                               // (gemm_wk_kernel: no slabs, no reduce launch); 0: never
   int prio_hi = 0;
@@ -911,6 +913,12 @@ int alloc_mimi_state(dsm_engine* e, MimiState* s, const MimiW& w, int B) {
 // ----------------------------------------------------------------------------------------------
 // GEMM launch
 // ----------------------------------------------------------------------------------------------
+// whole-K-in-the-workgroup GEMMs (dsm_gemm_wk.h): dot_mode 1, bf16 weights, at most four K-chunks (DSM_WK_GATE_CHUNKS), M <= 64
+bool wk_applicable(const dsm_engine* e, bool bf16_weights, int Kpad, int K, int M) {
+  const int chunks = (Kpad + DSM_KC - 1) / DSM_KC;
+  return bf16_weights && e->dot_mode == 1 && K % 32 == 0 && Kpad == K && chunks <= e->wk_gate_max_chunks && chunks <= 4 && M <= 64;
+}
+
 template <typename WT, typename KVT, int EPI, int NT>
 int launch_gemm_tiled(dsm_engine* e, hipStream_t st, GemmArgs& a) {
   int chunks = (a.Kpad + DSM_KC - 1) / DSM_KC;
@@ -924,21 +932,40 @@ int launch_gemm_tiled(dsm_engine* e, hipStream_t st, GemmArgs& a) {
     a.defer_reduce = 0;
     chunks = 1;
   }
-  // r04: a gated-MLP input GEMM with a short reduction (the DepFormer's: K = 1024) keeps the whole K inside the workgroup —
-  // four waves, one chunk each, a (gate, up) tile pair x 16 rows per workgroup, the SiLU gate behind the ordered LDS sum:
-  // no slabs, no reduce launch.  experiments/gemm_wk_probe: 7.5 us against 13.4 (10.9 with gemm_bx3u_kernel) at M = 32; at
-  // K = 2048 the activation re-read (every workgroup reads 16 x K x 4 bytes from L2) makes it lose (27 against 20 us).
-  if (EPI == EPI_GATE && NT == 2 && sizeof(WT) == 2 && e->dot_mode == 1 && a.chunk_loop == 0 && chunks > 1 &&
-      chunks <= e->wk_gate_max_chunks && chunks <= 4 && a.M <= 64 && a.N % 16 == 0) {
-    auto ok4 = [](const RowMap& m) { return m.ld % 4 == 0 && m.bstride % 4 == 0; };
-    a.vec = (a.N % 4 == 0) && (!a.Y || ok4(a.ymap));
-    a.ts = e->timeline ? e->dev_ts_slot(e->tag_gemm[e->sid(st)], e->sid(st), 1, 2) : nullptr;
-    const int ph = e->prof_begin(e->tag_gemm[e->sid(st)], st);
-    hipLaunchKernelGGL((gemm_wk_kernel<KVT, 1, 2, EPI_GATE, 1, 4, 2, true, 4>), dim3(a.N / 16, 1, (a.M + 15) / 16), dim3(256),
-                       (size_t)chunks * 2 * 1024, st, a);
-    e->prof_end(ph, st);
-    HIPCHK(hipGetLastError());
-    return 0;
+  // r04: short reductions (the DepFormer's: K = 1024) keep the whole K inside the workgroup — four waves, one chunk each,
+  // 16 rows x one (gate, up) tile pair (or one tile) per workgroup, the epilogue behind the ordered LDS sum: no slabs, no
+  // reduce launch.  experiments/gemm_wk_probe: gate 7.5 us against 13.4 (10.9 with gemm_bx3u_kernel) at M = 32; at K = 2048 the
+  // activation re-read (every workgroup reads 16 x K x 4 bytes from L2) makes it lose (27 against 20 us).  With
+  // a.pre_norm_w the row norm of the input runs in the kernel's prologue (gemm_wkn_kernel) and the norm launch goes too.
+  {
+    const bool wk_can = wk_applicable(e, sizeof(WT) == 2, a.Kpad, a.K, a.M) && a.chunk_loop == 0 && chunks > 1 && a.N % 16 == 0;
+    const bool wk = wk_can && ((EPI == EPI_GATE && NT == 2) ? true : (EPI == EPI_STORE && NT == 1 && a.wk_hint));
+    if (a.pre_norm_w && !(wk && EPI == EPI_GATE)) {
+      e->set_error("internal: a norm prologue was requested for a GEMM that does not run whole-K (K=%d M=%d)", a.K, a.M);
+      return DSM_ERR_STATE;
+    }
+    if (wk) {
+      auto ok4 = [](const RowMap& m) { return m.ld % 4 == 0 && m.bstride % 4 == 0; };
+      a.vec = (a.N % 4 == 0) && (!a.Y || ok4(a.ymap)) && (!a.Y2 || ok4(a.y2map)) && (!a.res || ok4(a.rmap));
+      a.ts = e->timeline ? e->dev_ts_slot(e->tag_gemm[e->sid(st)], e->sid(st), 1, 2) : nullptr;
+      const int ph = e->prof_begin(e->tag_gemm[e->sid(st)], st);
+      const dim3 grid(a.N / 16, 1, (a.M + 15) / 16);
+      if (EPI == EPI_GATE && a.pre_norm_w && a.pre_norm_rms)
+        hipLaunchKernelGGL((gemm_wkn_kernel<KVT, 2, EPI_GATE, true>), grid, dim3(256), (size_t)chunks * 2 * 1024 + 512 + 8192, st, a);
+      else if (EPI == EPI_GATE && a.pre_norm_w)
+        hipLaunchKernelGGL((gemm_wkn_kernel<KVT, 2, EPI_GATE, false>), grid, dim3(256), (size_t)chunks * 2 * 1024 + 512 + 8192, st, a);
+      else if (EPI == EPI_GATE)
+        hipLaunchKernelGGL((gemm_wk_kernel<KVT, 1, 2, EPI_GATE, 1, 4, 2, true, 4>), grid, dim3(256), (size_t)chunks * 2 * 1024, st, a);
+      else
+        hipLaunchKernelGGL((gemm_wk_kernel<KVT, 1, 1, EPI_STORE, 1, 4, 2, true, 4>), grid, dim3(256), (size_t)chunks * 1024, st, a);
+      e->prof_end(ph, st);
+      HIPCHK(hipGetLastError());
+      if (a.norm_out) {
+        hipLaunchKernelGGL(row_norm_kernel, dim3(a.M), dim3(256), 0, st, a.norm_out, a.Y, a.norm_w, a.norm_b, a.M, a.N, a.norm_eps, a.norm_rms);
+        HIPCHK(hipGetLastError());
+      }
+      return 0;
+    }
   }
   int MT = a.M > 32 ? 4 : (a.M > 16 ? 2 : 1);
   while (MT > 1 && (long)gx * chunks * ((a.M + 16 * MT - 1) / (16 * MT)) < 256) MT /= 2;  // cover the 256 CUs

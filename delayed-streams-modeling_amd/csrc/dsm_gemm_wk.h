@@ -340,3 +340,162 @@ __global__ __launch_bounds__(256, 2) void gemm_bx3u_kernel(GemmArgs a) {
 #undef DSM_STAMP
 #undef DSM_STAMP_WAIT
 }
+
+// ---- gemm_wk_kernel with the row norm of its input in the prologue (r04) -----------------------------------------------------
+// The GEMM that follows a norm reads the whole rows anyway when the whole K lives in the workgroup — so the norm launch (and the
+// xn round trip) goes: X is the raw residual stream, every workgroup computes the statistics of ITS 16 rows in the canonical
+// order of row_norm_kernel (dsm_numerics.h, ROW SUM) and normalises on the way into the B operand.  d = K <= 1024: thread t of
+// the canonical 256 owns elements 4t .. 4t+3, so canonical wave w IS this kernel's wave w (chunk w = columns 256 w ..), and a
+// lane (r, q) holds, for block i and half e, the four elements of canonical lane L = 8 i + 2 q + e of row r: the xor butterfly
+// 32, 16, 8, 4, 2, 1 over L is a sum over i (bits 2, 1, 0 of i: in registers), q (lanes ^ 32, ^ 16) and e (in registers), in that
+// order — a + b is commutative, so the tree gives every lane the bits the butterfly gives; wave totals meet in LDS and are added
+// left to right.  Then (x / mm) * w, or ((x - mean) * inv) * w + b: the arithmetic of row_norm_apply.
+// Four waves, one chunk each (a wave beyond the last chunk contributes +0 totals), 16 rows x 16 NT columns per workgroup,
+// dot_mode 1 only.  Every load — activations, norm weights, weight fragments — is issued before the first wait.
+// The norm weights (and LayerNorm bias) of a wave's chunk — 256 floats, the same for its 16 rows — travel as one float4 per lane
+// into wave-private LDS and are read back as broadcasts: 4 registers instead of 64.
+template <typename KVT, int NT, int EPI, bool RMS>
+__global__ __launch_bounds__(256, 2) void gemm_wkn_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float wk_part[];  // [chunks][NT][64][4] partial tiles, [2][4][16] wave totals, [2][4][256] norm w / b
+  launch_stamp_begin(a.ts);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int m_base = blockIdx.z * 16;
+  const int n_base = blockIdx.x * ((EPI == EPI_GATE) ? 16 : 16 * NT);
+  const int chunks = (a.Kpad + DSM_KC - 1) / DSM_KC;  // <= 4
+  const int kb0 = wave * 8;
+  const int nkb = min(8, (a.Kpad >> 5) - kb0);  // <= 0: no chunk for this wave
+  float* red = wk_part + chunks * NT * 256;
+  float* nws = red + 128 + wave * 256;
+  float* nbs = red + 128 + 1024 + wave * 256;
+  const uint16_t* W = reinterpret_cast<const uint16_t*>(a.W);
+  const int d = a.K;
+  float4 xv[8][2];
+  uint4 wv[8][NT];
+  if (nkb > 0) {
+    int m = m_base + r;
+    m = m < a.M ? m : a.M - 1;
+    const float* xrow = a.X + a.xmap.off(m) + 8 * q + 32 * kb0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int kb = 32 * (i < nkb ? i : nkb - 1);
+      xv[i][0] = *reinterpret_cast<const float4*>(xrow + kb);
+      xv[i][1] = *reinterpret_cast<const float4*>(xrow + kb + 4);
+    }
+    {
+      int k = 32 * kb0 + 4 * lane;
+      k = k + 4 <= d ? k : d - 4;  // a partial last chunk: the tail lanes re-read the last four weights, which no block uses
+      const float4 w4 = *reinterpret_cast<const float4*>(a.pre_norm_w + k);
+      *reinterpret_cast<float4*>(nws + 4 * lane) = w4;
+      if (!RMS) *reinterpret_cast<float4*>(nbs + 4 * lane) = *reinterpret_cast<const float4*>(a.pre_norm_b + k);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int kb = 32 * (i < nkb ? i : nkb - 1);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        wv[i][nt] = *reinterpret_cast<const uint4*>(W + (long)(n_base + nt * a.nt_stride + r) * a.Kpad + 8 * q + 32 * kb0 + kb);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // canonical lane (i, q, e): chain over its four elements from +0
+  float s = 0.0f, s2 = 0.0f;
+  {
+    float ps[8][2], ps2[8][2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        float cs = 0.0f, cs2 = 0.0f;
+        if (i < nkb) {
+          const float4 v = xv[i][e];
+          cs = cs + v.x; cs2 = DSM_FMAF(v.x, v.x, cs2);
+          cs = cs + v.y; cs2 = DSM_FMAF(v.y, v.y, cs2);
+          cs = cs + v.z; cs2 = DSM_FMAF(v.z, v.z, cs2);
+          cs = cs + v.w; cs2 = DSM_FMAF(v.w, v.w, cs2);
+        }
+        ps[i][e] = cs; ps2[i][e] = cs2;
+      }
+    // butterfly offsets 32, 16, 8 of L: bits 2, 1, 0 of the block index
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { ps[i][e] = ps[i][e] + ps[i + 4][e]; ps2[i][e] = ps2[i][e] + ps2[i + 4][e]; }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { ps[i][e] = ps[i][e] + ps[i + 2][e]; ps2[i][e] = ps2[i][e] + ps2[i + 2][e]; }
+      ps[0][e] = ps[0][e] + ps[1][e]; ps2[0][e] = ps2[0][e] + ps2[1][e];
+      // offsets 4, 2: the two bits of q = lane bits 5, 4
+      ps[0][e] = ps[0][e] + __shfl_xor(ps[0][e], 32, 64); ps2[0][e] = ps2[0][e] + __shfl_xor(ps2[0][e], 32, 64);
+      ps[0][e] = ps[0][e] + __shfl_xor(ps[0][e], 16, 64); ps2[0][e] = ps2[0][e] + __shfl_xor(ps2[0][e], 16, 64);
+    }
+    s = ps[0][0] + ps[0][1];  // offset 1
+    s2 = ps2[0][0] + ps2[0][1];
+  }
+  if (q == 0) { red[wave * 16 + r] = s; red[64 + wave * 16 + r] = s2; }
+  __syncthreads();
+  s = ((red[r] + red[16 + r]) + red[32 + r]) + red[48 + r];
+  s2 = ((red[64 + r] + red[80 + r]) + red[96 + r]) + red[112 + r];
+  float mm = 1.f, mean = 0.f, inv = 0.f;
+  if (RMS) {
+    mm = sqrtf(s2 / (float)d + a.pre_norm_eps);
+  } else {
+    mean = s / (float)d;
+    const float var = s2 / (float)d - mean * mean;
+    inv = 1.0f / sqrtf(var + a.pre_norm_eps);
+  }
+  f32x4 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (nkb > 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (i < nkb) {  // wave-uniform
+        float4 xn[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const float4 v = xv[i][e], w4 = *reinterpret_cast<const float4*>(nws + 32 * i + 8 * q + 4 * e);
+          if (RMS) {
+            xn[e].x = (v.x / mm) * w4.x; xn[e].y = (v.y / mm) * w4.y; xn[e].z = (v.z / mm) * w4.z; xn[e].w = (v.w / mm) * w4.w;
+          } else {
+            const float4 b4 = *reinterpret_cast<const float4*>(nbs + 32 * i + 8 * q + 4 * e);
+            xn[e].x = ((v.x - mean) * inv) * w4.x + b4.x; xn[e].y = ((v.y - mean) * inv) * w4.y + b4.y;
+            xn[e].z = ((v.z - mean) * inv) * w4.z + b4.z; xn[e].w = ((v.w - mean) * inv) * w4.w + b4.w;
+          }
+        }
+        dsm_bf16x8 xp[3];
+        dsm_split3_pack8(xn[0], xn[1], xp[0], xp[1], xp[2]);
+        dsm_bf16x8 wa[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const dsm_u32x4v t = {wv[i][nt].x, wv[i][nt].y, wv[i][nt].z, wv[i][nt].w};
+          wa[nt] = __builtin_bit_cast(dsm_bf16x8, t);
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p)  // lo, mid, hi
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[nt], xp[p], acc[nt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<f32x4*>(&wk_part[((wave * NT + nt) * 64 + lane) * 4]) = acc[nt];
+  }
+  __syncthreads();
+  constexpr int OUT = (EPI == EPI_GATE) ? 1 : NT;
+#pragma unroll
+  for (int t = 0; t < OUT; ++t) {
+    if ((t % 4) != wave) continue;
+    if (EPI == EPI_GATE) {
+      f32x4 g = (f32x4){0.f, 0.f, 0.f, 0.f}, u = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int c = 0; c < chunks; ++c) {
+        g = g + *reinterpret_cast<const f32x4*>(&wk_part[((c * NT) * 64 + lane) * 4]);
+        u = u + *reinterpret_cast<const f32x4*>(&wk_part[((c * NT + NT - 1) * 64 + lane) * 4]);
+      }
+      epi_gate(a, g, u, m_base + r, n_base + 4 * q);
+    } else {
+      f32x4 tot = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int c = 0; c < chunks; ++c) tot = tot + *reinterpret_cast<const f32x4*>(&wk_part[((c * NT + t) * 64 + lane) * 4]);
+      epi_store_qkv<KVT, EPI>(a, tot, m_base + r, n_base + t * a.nt_stride + 4 * q);
+    }
+  }
+  launch_stamp_end(a.ts);
+}

@@ -81,6 +81,12 @@ struct GemmArgs {
   float* norm_out;
   float norm_eps;
   int norm_rms;
+  int wk_hint;  // host side: prefer the whole-K-in-the-workgroup form (gemm_wk_kernel) for this EPI_STORE launch
+  // optional row norm IN FRONT of the GEMM (gemm_wkn_kernel): X is the un-normalised stream, d = K
+  const float* pre_norm_w;
+  const float* pre_norm_b;
+  float pre_norm_eps;
+  int pre_norm_rms;
   // optional device-clock bracket of the launch (timeline diagnostics, dsm_prof_timeline): {first workgroup in, last out}
   unsigned long long* ts;
 };

@@ -344,6 +344,11 @@ int dsm_debug_serialize_groups(dsm_engine*, int on);
  * untouched) so that short profiler runs see steady-state attention traffic.  Never used for `value`. */
 int dsm_debug_set_positions(dsm_engine*, uint32_t lm_pos, uint32_t mimi_pos);
 
+/* Test aid (teacher forcing): overwrite the text token every slot feeds back into its next step (core/asr.rs:147-160, the
+ * `text_token` of State) with `tokens` [batch].  tests/test_dot_mode_agreement_gpu.py drives a dot_mode 1 engine along a
+ * dot_mode 0 engine's token history with it, so that one flipped argmax does not cascade. */
+int dsm_debug_set_text_tokens(dsm_engine*, const uint32_t* tokens);
+
 /* Debug taps for the parity tests: copy a named intermediate of the last step to the host.
  * Names: "lm.hidden" [B,d], "lm.logits" [B,V], "mimi.seanet_out" [B,T,dim], "mimi.latent" [B,dim] ...
  * Returns the number of floats written, or <0. */

@@ -86,14 +86,18 @@ def test_seanet_front_fused_and_as_three_launches(gpu, dsm, lib, orc, full_weigh
     ora.close()
 
 
-def test_full_size_steady_state_wrapped_ring(gpu, dsm, lib, orc, full_weights):
-    """The benchmarked regime itself, at the real dimensions: every ring is jumped past its context (`debug_set_positions` on
+@pytest.mark.parametrize("dot_mode", [0, 1])
+def test_full_size_steady_state_wrapped_ring(gpu, dsm, lib, orc, full_weights, dot_mode):
+    """Both canonical dot products (dot_mode 1 is what bench.py times: gemm_bx3u_kernel's split-K slabs + the attention prologue).
+    The benchmarked regime itself, at the real dimensions: every ring is jumped past its context (`debug_set_positions` on
     both sides: 3 x 750 + 11 LM frames, 3 x 250 + 5 Mimi frames — wrapped, every one of the 750 / 250 slots visible, write
     index mid-ring) and the engine is compared with the oracle on full-length attention — hd 128 bf16 with six pipelined
     iterations per phase in the LM, hd 64 f32 T = 2 in Mimi — through frames that overwrite ring slots, with a paused slot and
     the fused QKV prologue writing the new K/V row into a full ring.  Bits: latents, codes, LM hidden state, logits, tokens, VAD."""
     from dsm_amd import synth
     cfg, (lm, mimi) = full_weights
+    cfg = type(cfg).from_buffer_copy(cfg)
+    cfg.dot_mode = dot_mode
     B, steps = 3, 3
     eng = dsm.AsrEngine(cfg, B, lm, mimi)
     ora = orc.OracleAsr(cfg, B, lm, mimi)

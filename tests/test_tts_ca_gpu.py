@@ -116,3 +116,28 @@ def test_cross_attention_and_guidance_at_v202501_shapes(gpu, dsm, lib, orc):
         _drive(dsm, orc, cfg, path, B, 3, setup, sampling={2: (50, 0.6, 7)})
     finally:
         os.remove(path)  # 1.1 GB
+
+
+def test_source_only_on_a_fresh_slot_and_ca_checkpoint_needs_ca_config(gpu, dsm, lib):
+    """(1) a slot that has generated steps refuses a new source / guidance until it is reset (the reference fixes
+    ca_src and the batch size at State::new, core/tts_streaming.rs:100-115), clearing stays allowed; (2) a checkpoint that
+    carries cross_attention.* tensors is refused by an engine configured without cross attention instead of skipping them."""
+    from dsm_amd import synth
+    from tts_schedule import schedule
+    cfg, path = _cfg(dsm, cfg_rows=True)
+    B = 2
+    eng = dsm.TtsEngine(cfg, B, path)
+    eng.set_ca_src(0, synth.synth_ca_src(cfg, 8, 1))
+    for s, (prev, allowed, mask) in enumerate(schedule(cfg, B, 3)):
+        eng.step(prev, allowed, mask)
+    with pytest.raises(dsm.DsmError, match="fresh slot"):
+        eng.set_ca_src(0, synth.synth_ca_src(cfg, 8, 1), synth.synth_ca_src(cfg, 8, 2), 2.0)
+    with pytest.raises(dsm.DsmError, match="fresh slot"):
+        eng.set_ca_src(1, synth.synth_ca_src(cfg, 5, 3))
+    eng.set_ca_src(0, None)  # clearing is allowed at any step
+    eng.reset_batch_idx(1)
+    eng.set_ca_src(1, synth.synth_ca_src(cfg, 5, 3))
+    eng.close()
+    plain = dsm.config_tts_tiny()
+    with pytest.raises(dsm.DsmError, match="cross_attention"):
+        dsm.TtsEngine(plain, B, path)
