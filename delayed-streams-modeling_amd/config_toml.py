@@ -85,8 +85,8 @@ def load_batched_asr(path, module=None):
         raise ConfigError(f"dtype_override {dt!r}: only bf16 and f32 exist on this engine")
     cfg.kv_bf16 = 0 if dt == "f32" else 1
     # extension key of this engine (absent in the reference's tomls): which canonical dot product the bf16-weight GEMMs use
-    # (include/dsm.h, dsm_asr_config.dot_mode); 0 unless the deployment opts in
-    dm = m.get("dot_mode", 0)
+    # (include/dsm.h, dsm_asr_config.dot_mode); 1 — the presets' and bench.py's mode — unless the toml says 0
+    dm = m.get("dot_mode", 1)
     if dm not in (0, 1):
         raise ConfigError(f"dot_mode {dm!r}: 0 (f32 fma chain) or 1 (bf16 matrix instruction over the exact three-way split)")
     cfg.dot_mode = int(dm)

@@ -52,6 +52,9 @@ static inline void dsm_preset_stt_common(dsm_asr_config* c) {
   c->audio_codebooks = 32;
   c->temperature = 0.0f;
   c->kv_bf16 = 1;
+  c->dot_mode = 1; /* r04: the shipped presets select the bf16 matrix instruction ("bx3", include/dsm.h) — the mode bench.py times;
+                      against dot_mode 0 at these dimensions: logits within 1.4e-6 (f32 ring) / 1.8e-4 (bf16 ring) of the row's
+                      largest, 480 / 480 text tokens equal (tests/test_dot_mode_agreement_gpu.py, profiles/r04/dot_mode_agreement.json) */
   dsm_preset_mimi_v0_1(&c->mimi, 32); /* srv/batched_asr.rs:754-757: Config::v0_1(Some(audio_codebooks)) */
 }
 
@@ -100,5 +103,6 @@ static inline void dsm_preset_tts_v202501(dsm_tts_config* c) {
    * reference runs.  Sources: speaker_cond_n_speakers = 5 x 25 rows at 12.5 Hz -> 125 rows; 128 fit.  Guidance
    * (two batch rows per slot, cfg_alpha) stays opt-in through cfg_rows, as it is per request in the reference. */
   c->cross_attention = 1; c->ca_norm = 0; c->ca_dim = 0; c->ca_max_len = 128; c->cfg_rows = 0;
+  c->dot_mode = 1; /* as the STT presets */
 }
 #endif

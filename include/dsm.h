@@ -97,7 +97,9 @@ typedef struct dsm_asr_config {
    *   1  "bx3" (r03): the f32 activation split exactly into three bf16 pieces, v_mfma_f32_16x16x32_bf16 on (weight, piece)
    *      per 32-wide block in the order lo, mid, hi; the instruction's internal adder as modelled in
    *      csrc/dsm_bf16_mfma_model.h (validated on the hardware: experiments/bf16_adder_probe.hip).  Every product is exact; the
-   *      matrix pipe does a third of the cycles per k ... at 16 x the rate */
+   *      matrix pipe does a third of the cycles per k ... at 16 x the rate.
+   * The presets below (and config_toml's default) select 1, the mode bench.py times; tests/test_dot_mode_agreement_gpu.py bounds
+   * its distance from mode 0 at the real dimensions. */
   int dot_mode;
 } dsm_asr_config;
 

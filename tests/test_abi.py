@@ -79,3 +79,11 @@ def test_safetensors_key_map(dsm, tiny_weights):
               "quantizer.rvq_first.vq.layers.0._codebook.cluster_usage"):
         assert k in mimi, k
     assert lm["transformer.layers.0.norm1.alpha"].shape == (1, 1, 128)
+
+
+def test_presets_select_dot_mode_1_and_the_reference_tts_branch(dsm, lib):
+    """r04: the shipped presets are what bench.py times (dot_mode 1) and, for TTS, the branch the reference server runs
+    (tts_202501: cross attention in every layer, core/lm.rs:392-396)."""
+    assert dsm.config_stt_1b_en_fr().dot_mode == 1 and dsm.config_stt_2_6b_en().dot_mode == 1
+    t = dsm.config_tts_v202501()
+    assert (t.dot_mode, t.cross_attention, t.ca_norm, t.ca_dim, t.ca_max_len, t.cfg_rows) == (1, 1, 0, 0, 128, 0)

@@ -43,6 +43,7 @@ def test_large_batch_slots_with_equal_audio_agree_and_match_b4(gpu, dsm, lib, mo
     on 8192-workgroup launches, K = 2048 / 8192 loop GEMMs over 4 m-tiles per group."""
     from dsm_amd import synth
     cfg = dsm.config_stt_1b_en_fr() if model == "stt-1b-en_fr" else dsm.config_stt_2_6b_en()
+    cfg.dot_mode = 0  # the preset says 1; this file runs mode 0 (mode 1 at these shapes: test_bx3_gpu.py)
     lm, mimi = synth.make_synth_weights(cfg, WEIGHTS_DIR, tag=model)
     NS, steps = 4, 4
     rng = np.random.default_rng(21)
@@ -93,6 +94,7 @@ def test_tts_b384_slots_with_equal_inputs_agree_and_match_b3(gpu, dsm, lib):
     top-k slots alike, through a paused step."""
     from dsm_amd import synth
     cfg = dsm.config_tts_v202501()
+    cfg.dot_mode = 0  # the preset says 1; this file runs mode 0 (mode 1 at these shapes: test_bx3_gpu.py)
     cfg.text_audio_delay_in_tokens, cfg.max_steps = 0, 32  # depformer live from the first step
     path = synth.make_synth_tts_weights(cfg, WEIGHTS_DIR, tag="tts-v202501-prop")
     B, NS, steps = 384, 3, 5

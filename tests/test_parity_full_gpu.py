@@ -13,6 +13,7 @@ def full_weights(dsm):
     from dsm_amd import synth
     import os
     cfg = dsm.config_stt_1b_en_fr()
+    cfg.dot_mode = 0  # the preset says 1 (r04); the tests of this file name the mode they run (dot_mode 1: test_bx3_gpu.py and the parametrised ones)
     return cfg, synth.make_synth_weights(cfg, os.environ.get("DSM_WEIGHTS_DIR", "/tmp/dsm_weights"), tag="stt-1b-en_fr")
 
 
@@ -131,6 +132,7 @@ def test_stt_2_6b_en_shapes(gpu, dsm, lib, orc):
     import os
     from dsm_amd import synth
     cfg = dsm.config_stt_2_6b_en()
+    cfg.dot_mode = 0  # then the same step in dot_mode 1 below
     lm, mimi = synth.make_synth_weights(cfg, os.environ.get("DSM_WEIGHTS_DIR", "/tmp/dsm_weights"), tag="stt-2.6b-en")
     B = 2
     eng = dsm.AsrEngine(cfg, B, lm, mimi)
@@ -193,6 +195,7 @@ def test_tts_v202501_shapes(gpu, dsm, lib, orc):
     import os
     from dsm_amd import synth
     cfg = dsm.config_tts_v202501()
+    cfg.dot_mode = 0  # dot_mode 1 at these shapes: test_tts_ca_gpu.py::test_cross_attention_and_guidance_at_v202501_shapes
     cfg.text_audio_delay_in_tokens, cfg.max_steps = 3, 64
     path = synth.make_synth_tts_weights(cfg, os.environ.get("DSM_WEIGHTS_DIR", "/tmp/dsm_weights"), tag="tts-v202501")
     B = 2

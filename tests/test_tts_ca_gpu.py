@@ -99,6 +99,7 @@ def test_cross_attention_and_guidance_at_v202501_shapes(gpu, dsm, lib, orc):
     three slots = six batch rows, sources of 5 x 25 rows (speaker_cond_n_speakers x 2 s at 12.5 Hz), guidance on two slots."""
     from dsm_amd import synth
     cfg = dsm.config_tts_v202501()
+    cfg.dot_mode = 0
     cfg.text_audio_delay_in_tokens, cfg.max_steps = 2, 64
     cfg.cross_attention, cfg.ca_norm, cfg.ca_dim, cfg.ca_max_len, cfg.cfg_rows = 1, 0, 0, 128, 1
     path = synth.make_synth_tts_weights(cfg, WDIR, tag="tts-v202501-ca")

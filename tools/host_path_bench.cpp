@@ -12,7 +12,7 @@
 // the per-thread busy times say which side is the limit.  Ring caches are jumped to the steady state first
 // (dsm_debug_set_positions), like the device-resident legs.
 //
-// usage: host_path_bench <lm.safetensors> <mimi.safetensors> <batch> <frames> [feeder threads = 8] [dot_mode = 0]   (stt-1b-en_fr)
+// usage: host_path_bench <lm.safetensors> <mimi.safetensors> <batch> <frames> [feeder threads = 8] [dot_mode = 1]   (stt-1b-en_fr)
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -31,7 +31,7 @@ int main(int argc, char** argv) {
   const int B = atoi(argv[3]), frames = atoi(argv[4]), F = argc > 5 ? atoi(argv[5]) : 8;
   dsm_asr_config cfg;
   dsm_asr_config_stt_1b_en_fr(&cfg);
-  cfg.dot_mode = argc > 6 ? atoi(argv[6]) : 0;
+  cfg.dot_mode = argc > 6 ? atoi(argv[6]) : 1;
   dsm_engine* e = nullptr;
   if (dsm_asr_create(&cfg, 0, B, argv[1], argv[2], &e)) { fprintf(stderr, "create: %s\n", dsm_last_error(nullptr)); return 2; }
   dsm_worker* w = nullptr;
