@@ -122,7 +122,8 @@ ABI_SYMBOLS = [
     "dsm_streams_join", "dsm_debug_read", "dsm_asr_step_pcm_dev", "dsm_prof_enable", "dsm_prof_read",
     "dsm_debug_set_positions", "dsm_debug_set_text_tokens", "dsm_mimi_decode_step", "dsm_mimi_decode_step_dev",
     "dsm_lm_stream_groups", "dsm_debug_serialize_groups", "dsm_prof_read_device", "dsm_prof_timeline", "dsm_prof_timeline_read",
-    "dsm_wav_decode", "dsm_free", "dsm_linear_resampler_new", "dsm_linear_resampler_process",
+    "dsm_wav_decode", "dsm_mp3_decode", "dsm_mp3_decode_info", "dsm_mp3_probe", "dsm_resample", "dsm_pcm_decode",
+    "dsm_mp3_test_synth", "dsm_mp3_test_tables", "dsm_mp3_test_imdct", "dsm_free", "dsm_linear_resampler_new", "dsm_linear_resampler_process",
     "dsm_linear_resampler_free", "dsm_ogg_demux_new", "dsm_ogg_demux_free", "dsm_ogg_demux_push", "dsm_ogg_demux_next",
     "dsm_ogg_demux_info", "dsm_worker_set_opus_decoder", "dsm_ogg_mux_new", "dsm_ogg_mux_free", "dsm_ogg_mux_header", "dsm_ogg_mux_page",
     "dsm_inmsg_encode", "dsm_outmsg_encode", "dsm_inmsg_decode", "dsm_outmsg_decode", "dsm_worker_create",
@@ -200,6 +201,18 @@ def load_library(path=None):
     lib.dsm_wav_decode.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_size_t),
                                    C.POINTER(C.c_int)]
     lib.dsm_wav_decode.restype = C.c_int
+    for name in ("dsm_mp3_decode", "dsm_pcm_decode"):
+        getattr(lib, name).argtypes = lib.dsm_wav_decode.argtypes
+        getattr(lib, name).restype = C.c_int
+    lib.dsm_mp3_decode_info.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_size_t), C.POINTER(Mp3Info)]
+    lib.dsm_mp3_decode_info.restype = C.c_int
+    lib.dsm_mp3_probe.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Mp3Info)]
+    lib.dsm_mp3_probe.restype = C.c_int
+    lib.dsm_resample.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_size_t)]
+    lib.dsm_resample.restype = C.c_int
+    lib.dsm_mp3_test_synth.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.dsm_mp3_test_tables.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_int]
+    lib.dsm_mp3_test_imdct.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.dsm_free.argtypes = [vp]
     lib.dsm_free.restype = None
     lib.dsm_linear_resampler_new.argtypes = [C.c_uint32, C.c_uint32]
@@ -519,6 +532,65 @@ class Worker:
             self.close()
         except Exception:
             pass
+
+
+class Mp3Info(C.Structure):
+    _fields_ = [("sample_rate", C.c_int), ("channels", C.c_int), ("bitrate_kbps", C.c_int), ("vbr", C.c_int), ("frames", C.c_int),
+                ("info_frames", C.c_int), ("resyncs", C.c_int), ("huffman_overruns", C.c_int), ("frames_without_reservoir", C.c_int),
+                ("id3v2_bytes", C.c_uint64), ("junk_bytes", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+def _take_pcm(lib, ptr, n):
+    try:
+        return np.ctypeslib.as_array(ptr, shape=(n.value,)).copy() if n.value else np.zeros(0, np.float32)
+    finally:
+        lib.dsm_free(ptr)
+
+
+def mp3_decode(data):
+    """(pcm f32 of channel 0, sample_rate, info dict) of an MPEG-1 Layer III body — srv/utils.rs:263-305 pcm_decode (symphonia)."""
+    lib = load_library()
+    ptr, n, info = C.POINTER(C.c_float)(), C.c_size_t(0), Mp3Info()
+    rc = lib.dsm_mp3_decode_info(data, len(data), C.byref(ptr), C.byref(n), C.byref(info))
+    if rc != 0:
+        msg = lib.dsm_last_error(None)
+        raise DsmError(f"dsm_mp3_decode failed ({rc}): {msg.decode() if msg else '?'}")
+    return _take_pcm(lib, ptr, n), info.sample_rate, info.as_dict()
+
+
+def mp3_probe(data):
+    lib = load_library()
+    info = Mp3Info()
+    rc = lib.dsm_mp3_probe(data, len(data), C.byref(info))
+    if rc != 0:
+        msg = lib.dsm_last_error(None)
+        raise DsmError(f"dsm_mp3_probe failed ({rc}): {msg.decode() if msg else '?'}")
+    return info.as_dict()
+
+
+def pcm_decode(data):
+    """RIFF/WAVE or mp3 by magic: (pcm of channel 0, sample_rate) — what the worker front end does with a request body."""
+    lib = load_library()
+    ptr, n, rate = C.POINTER(C.c_float)(), C.c_size_t(0), C.c_int(0)
+    rc = lib.dsm_pcm_decode(data, len(data), C.byref(ptr), C.byref(n), C.byref(rate))
+    if rc != 0:
+        msg = lib.dsm_last_error(None)
+        raise DsmError(f"dsm_pcm_decode failed ({rc}): {msg.decode() if msg else '?'}")
+    return _take_pcm(lib, ptr, n), rate.value
+
+
+def resample(pcm, rate_in, rate_out):
+    """Whole-buffer windowed-sinc resampler in the place of kaudio::resample (srv/batched_asr.rs:838)."""
+    lib = load_library()
+    x = np.ascontiguousarray(pcm, dtype=np.float32)
+    ptr, n = C.POINTER(C.c_float)(), C.c_size_t(0)
+    rc = lib.dsm_resample(x.ctypes.data, x.size, int(rate_in), int(rate_out), C.byref(ptr), C.byref(n))
+    if rc != 0:
+        raise DsmError(f"dsm_resample failed ({rc})")
+    return _take_pcm(lib, ptr, n)
 
 
 def wav_decode(data):

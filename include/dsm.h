@@ -361,9 +361,37 @@ int dsm_debug_read(dsm_engine*, const char* name, float* out, size_t cap);
  * dsm_wav_decode: channel 0 of a RIFF/WAVE body as f32 — what srv/utils.rs:263-305 `pcm_decode` hands the worker
  * (srv/batched_asr.rs:834-842) for such a body.  *pcm_out is malloc'd; release it with dsm_free.
  * dsm_linear_resampler_*: the clients' default resampler, client/rust/kyutai-client-core/src/audio.rs:133-183
- * (`LinearResampler::process_into`), streaming.  mp3 and the Opus codec are not built; the Ogg container is (below).
+ * (`LinearResampler::process_into`), streaming.  The Opus codec is the host's callback; the Ogg container and mp3 are built (below).
  * ------------------------------------------------------------------------------------------------ */
 int dsm_wav_decode(const uint8_t* bytes, size_t len, float** pcm_out, size_t* n_out, int* sample_rate_out);
+
+/* r04 — the rest of srv/utils.rs:263-305 `pcm_decode` for the bodies the reference's own samples use (audio/bria.mp3 of
+ * BASELINE.json configs[0], loona.mp3, sample_fr_hibiki_*.mp3) and srv/batched_asr.rs:834-842 `kaudio::resample(&pcm, rate, 24000)`:
+ *   dsm_mp3_decode   MPEG-1 Audio Layer III (ISO/IEC 11172-3; mono, stereo, joint stereo; bit reservoir; ID3v2 / Xing / ID3v1
+ *                    skipped as symphonia's reader does), channel 0 as f32 in [-1, 1], no gapless trimming (FormatOptions::default()).
+ *                    symphonia is an un-vendored crate and no decoder is importable offline: PARITY UNPINNED against it; the
+ *                    tables and the filter bank are pinned by their defining properties (tests/test_mp3.py).  MPEG-2 / 2.5 and
+ *                    Layers I / II: DSM_ERR_IO.
+ *   dsm_mp3_probe    the frame walk alone (headers + side information): counts, bit rate, sync losses.
+ *   dsm_resample     whole-buffer polyphase windowed-sinc resampler for a rational ratio (Kaiser, 32 zero crossings, cut-off
+ *                    0.95 of the lower Nyquist) in the place of kaudio::resample (un-vendored; parity unpinned).
+ *   dsm_pcm_decode   RIFF/WAVE or mp3 by magic — the call the worker front end makes on a request body.
+ * Outputs are malloc'd (dsm_free). */
+typedef struct dsm_mp3_info {
+  int sample_rate, channels, bitrate_kbps /* first frame */, vbr;
+  int frames;       /* audio frames (1152 samples each); a leading Xing / Info / VBRI frame is metadata and not counted */
+  int info_frames, resyncs, huffman_overruns, frames_without_reservoir;
+  uint64_t id3v2_bytes, junk_bytes; /* junk: bytes skipped between frames after the first one (sync losses) */
+} dsm_mp3_info;
+int dsm_mp3_decode(const uint8_t* bytes, size_t len, float** pcm_out, size_t* n_out, int* sample_rate_out);
+int dsm_mp3_decode_info(const uint8_t* bytes, size_t len, float** pcm_out, size_t* n_out, dsm_mp3_info* info);
+int dsm_mp3_probe(const uint8_t* bytes, size_t len, dsm_mp3_info* out);
+int dsm_resample(const float* in, size_t n, int rate_in, int rate_out, float** out, size_t* n_out);
+int dsm_pcm_decode(const uint8_t* bytes, size_t len, float** pcm_out, size_t* n_out, int* sample_rate_out);
+/* test aids (tests/test_mp3.py): the synthesis bank, the Huffman tables and the IMDCT on their own */
+int dsm_mp3_test_synth(const float* subbands, int slots, float* pcm);
+int dsm_mp3_test_tables(int table, int* xlen, int* linbits, uint16_t* codes, uint8_t* lens, int cap);
+int dsm_mp3_test_imdct(const float* spectrum, int block_type, float* out);
 void dsm_free(void*);
 /* Ogg container demultiplexer (RFC 3533 pages -> RFC 7845 Opus packets) for InMsg::OggOpus bodies, the container half of
  * kaudio::ogg_opus::Decoder (srv/batched_asr.rs:894,941-949): streaming (bytes may be split anywhere), CRC-checked,

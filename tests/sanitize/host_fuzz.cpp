@@ -231,6 +231,75 @@ static void fuzz_worker() {
   dsm_worker_destroy(w);
 }
 
+// ---- MPEG-1 Layer III (csrc/dsm_mp3.inc) ----
+static void try_mp3(const Bytes& b) {
+  float* pcm = nullptr;
+  size_t n = 0;
+  dsm_mp3_info info;
+  if (dsm_mp3_decode_info(b.data(), b.size(), &pcm, &n, &info) == 0) {
+    volatile float acc = 0;
+    for (size_t i = 0; i < n; ++i) acc = acc + pcm[i];
+    REQUIRE(n == (size_t)info.frames * 1152);
+    if (n > 4096 && rnd() % 8 == 0) {  // and through the resampler now and then
+      float* r = nullptr; size_t nr = 0;
+      REQUIRE(dsm_resample(pcm, 4096, 44100, 24000, &r, &nr) == 0);
+      for (size_t i = 0; i < nr; ++i) acc = acc + r[i];
+      dsm_free(r);
+    }
+    dsm_free(pcm);
+  }
+  (void)dsm_mp3_probe(b.data(), b.size(), &info);
+  ++n_cases;
+}
+static void fuzz_mp3(const std::string& repo_audio) {
+  std::vector<Bytes> seeds;
+  for (const char* name : {"/loona.mp3", "/bria_head.mp3"}) {
+    FILE* f = fopen((repo_audio + name).c_str(), "rb");
+    REQUIRE(f != nullptr);
+    Bytes b(40000);  // loona whole; the first 95 frames of the other clip
+    b.resize(fread(b.data(), 1, b.size(), f));
+    fclose(f);
+    seeds.push_back(b);
+  }
+  {  // a synthetic stereo / joint-stereo stream: valid headers over random side information and main data
+    Bytes b;
+    for (int fr = 0; fr < 24; ++fr) {
+      const uint8_t mode = (uint8_t)(fr % 3 == 0 ? 0x00 : 0x40 | ((rnd() & 3) << 4));  // stereo, or joint stereo with any mode_ext
+      const uint8_t hdr[4] = {0xFF, (uint8_t)(0xFA | (rnd() & 1)), (uint8_t)(0x90 | ((rnd() % 3) << 2)), mode};
+      dsm_mp3::Header h;
+      REQUIRE(dsm_mp3::parse_header(hdr, &h));
+      b.insert(b.end(), hdr, hdr + 4);
+      for (int i = 4; i < h.frame_bytes; ++i) b.push_back((uint8_t)rnd());
+    }
+    seeds.push_back(b);
+  }
+  for (Bytes& s : seeds) {
+    try_mp3(s);
+    for (size_t cut = 0; cut <= s.size(); cut += cut < 600 ? 1 : 1 + rnd() % 997) try_mp3(Bytes(s.begin(), s.begin() + (long)cut));
+    for (int it = 0; it < 250; ++it) {
+      Bytes b = s;
+      const int edits = 1 + (int)(rnd() % 6);
+      for (int e = 0; e < edits; ++e) {
+        const size_t at = rnd() % b.size();
+        if (rnd() % 4 == 0) b[at] = (uint8_t)rnd(); else b[at] ^= (uint8_t)(1u << (rnd() % 8));
+      }
+      if (it % 5 == 0) b.resize(rnd() % (b.size() + 1));
+      if (it % 7 == 0) b.erase(b.begin(), b.begin() + (long)(rnd() % (b.size() / 2 + 1)));  // start mid-stream: the reservoir is missing
+      try_mp3(b);
+    }
+  }
+  Bytes junk(20000);
+  for (int it = 0; it < 200; ++it) {  // random bytes salted with sync words
+    for (auto& v : junk) v = (uint8_t)rnd();
+    for (int k = 0; k < 40; ++k) { const size_t at = rnd() % (junk.size() - 4); junk[at] = 0xFF; junk[at + 1] = 0xFB; junk[at + 2] = (uint8_t)(0x10 + (rnd() % 14) * 16); }
+    try_mp3(junk);
+  }
+  float* r = nullptr; size_t nr = 0;
+  REQUIRE(dsm_resample(nullptr, 0, 44100, 24000, &r, &nr) == 0 && nr == 0); dsm_free(r);
+  REQUIRE(dsm_resample(junk.empty() ? nullptr : (const float*)nullptr, 0, 0, 24000, &r, &nr) != 0);
+  REQUIRE(dsm_resample((const float*)junk.data(), 16, 44100, 44099, &r, &nr) != 0);  // L = 44099: refused, not a 2 GB table
+}
+
 // ---- RIFF/WAVE ----
 static Bytes make_wav(uint16_t fmt, uint16_t ch, uint32_t rate, uint16_t bits, size_t frames, bool extensible) {
   Bytes b;
@@ -337,7 +406,7 @@ static void fuzz_ogg() {
     Bytes pg = ogg_page(5, seq++, (p % 4 == 3) ? 1 : 0, lacing, body);
     stream.insert(stream.end(), pg.begin(), pg.end());
   }
-  for (int it = 0; it < 600; ++it) {
+  for (int it = 0; it < 250; ++it) {
     Bytes b = stream;
     const int edits = (int)(rnd() % 6);
     for (int e = 0; e < edits; ++e) {
@@ -540,6 +609,7 @@ int main(int argc, char** argv) {
   fuzz_msgpack(); lap("msgpack");
   fuzz_worker(); lap("worker");
   fuzz_wav(); lap("wav");
+  fuzz_mp3(argc > 2 ? argv[2] : "../golden/audio"); lap("mp3");
   fuzz_ogg(); lap("ogg");
   fuzz_safetensors(dir); lap("safetensors");
   printf("host_fuzz ok: %ld cases, no sanitizer report\n", n_cases);

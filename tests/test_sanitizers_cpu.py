@@ -1,6 +1,6 @@
 """CPU sanitizer recipe (AddressSanitizer + UBSan; the GPU pool has none):
   * tests/sanitize: host-only build of the parsers of untrusted bytes — msgpack + worker (csrc/dsm_worker.inc), RIFF/WAVE
-    (csrc/dsm_audio.inc), safetensors headers (csrc/dsm_safetensors.h) — driven with truncated, oversized, deeply nested
+    (csrc/dsm_audio.inc), MPEG-1 Layer III + resampler (csrc/dsm_mp3.inc), safetensors headers (csrc/dsm_safetensors.h) — driven with truncated, oversized, deeply nested
     and bit-flipped inputs (host_fuzz.cpp), including the 3 M-level nesting that used to overflow the stack;
   * `make -C oracle asan`: the CPU oracle itself, streamed through encode / LM / decode / TTS on the tiny configs."""
 import os
@@ -15,7 +15,7 @@ ENV = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stack
 def test_untrusted_input_parsers_under_asan_ubsan(tmp_path):
     d = os.path.join(ROOT, "tests", "sanitize")
     subprocess.check_call(["make", "-s", "-C", d, "host_fuzz"])
-    r = subprocess.run([os.path.join(d, "host_fuzz"), str(tmp_path)], capture_output=True, text=True, timeout=600, env=ENV)
+    r = subprocess.run([os.path.join(d, "host_fuzz"), str(tmp_path), os.path.join(ROOT, "tests", "golden", "audio")], capture_output=True, text=True, timeout=600, env=ENV)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "host_fuzz ok" in r.stdout
 
