@@ -128,7 +128,7 @@ ABI_SYMBOLS = [
     "dsm_ogg_demux_info", "dsm_worker_set_opus_decoder", "dsm_ogg_mux_new", "dsm_ogg_mux_free", "dsm_ogg_mux_header", "dsm_ogg_mux_page",
     "dsm_inmsg_encode", "dsm_outmsg_encode", "dsm_inmsg_decode", "dsm_outmsg_decode", "dsm_worker_create",
     "dsm_worker_create_with_backend", "dsm_worker_destroy", "dsm_worker_last_error", "dsm_worker_set_detokenizer", "dsm_worker_open", "dsm_worker_close",
-    "dsm_worker_send", "dsm_worker_step", "dsm_worker_step_encode", "dsm_worker_step_model",
+    "dsm_worker_send", "dsm_worker_send_body", "dsm_worker_step", "dsm_worker_step_encode", "dsm_worker_step_model",
     "dsm_mimi_encode_step_async", "dsm_asr_step_tokens_ticket", "dsm_worker_recv", "dsm_worker_buffered",
     "dsm_tts_config_v202501", "dsm_tts_create", "dsm_tts_destroy", "dsm_tts_last_error", "dsm_tts_step",
     "dsm_tts_audio_tokens", "dsm_tts_step_idx", "dsm_tts_reset_slot", "dsm_tts_debug_read", "dsm_tts_get_metrics", "dsm_tts_set_sampling",
@@ -491,6 +491,12 @@ class Worker:
         if rc < 0:
             raise DsmError(self._err())
         return rc == 0
+
+    def send_body(self, slot, body):
+        """BatchedAsr::handle_query: a whole audio file as the request (Init, the clip at 24 kHz, Marker 0, 10 s of silence)."""
+        rc = self.lib.dsm_worker_send_body(self.h, slot, body, len(body))
+        if rc < 0:
+            raise DsmError(self._err())
 
     def step(self):
         rc = self.lib.dsm_worker_step(self.h)

@@ -488,6 +488,9 @@ int dsm_worker_close(dsm_worker*, int slot);           /* the socket went away: 
  * larger than 64 MiB, or nested deeper than rmp_serde's limit of 1024: the reference logs and carries on),
  * DSM_ERR_STATE closed channel / OggOpus (no Opus decoder in this build). */
 int dsm_worker_send(dsm_worker*, int slot, const uint8_t* msgpack, size_t len);
+/* handle_query (srv/batched_asr.rs:811-851): a whole audio FILE (RIFF/WAVE or MPEG-1 Layer III) as the request on a freshly opened channel
+ * (dsm_worker_open queued the Init) — queues the decoded clip resampled to 24 kHz, Marker { id: 0 } and ten seconds of silence; the transcript is complete when the Marker returns. */
+int dsm_worker_send_body(dsm_worker*, int slot, const uint8_t* body, size_t len);
 /* One pass of encoder_loop -> model_loop -> post_process (:314-522) on the calling thread: 1 a step ran, 0 idle, <0 engine error. */
 int dsm_worker_step(dsm_worker*);
 /* The same work as the reference's threads split it (:314 encoder_loop, :432 model_loop + :414 post_process), for a host

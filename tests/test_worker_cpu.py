@@ -199,3 +199,44 @@ def test_ticketed_backend_whose_encode_fails_once(dsm, lib, orc, tiny_weights):
             assert wa.recv(slot) == wb.recv(slot)
     assert failed == 1 and not ring_a["in_flight"] and not ring_b["in_flight"]
     wa.close(); wb.close()
+
+
+def test_send_body_is_handle_query(dsm, lib, orc, tiny_weights):
+    """BatchedAsr::handle_query (srv/batched_asr.rs:811-851): an mp3 file as the request body = Audio { pcm_decode + resample to
+    24 kHz }, Marker { id: 0 }, ten seconds of silence — the same OutMsgs, in the same order, as those messages sent one by one,
+    and the transcript ends when the Marker comes back."""
+    import os
+    cfg = dsm.config_tiny()
+    B = 2
+    body = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "audio", "loona.mp3"), "rb").read()
+    pcm, rate, _ = dsm.mp3_decode(body)
+    pcm24 = dsm.resample(pcm, rate, 24000)
+    outs = []
+    for via_body in (True, False):
+        ora = orc.OracleAsr(cfg, B, *tiny_weights)
+        be, keep = worker_ref.oracle_backend(dsm, ora, cfg, B)
+        w = dsm.Worker(backend=be, detokenizer=lambda toks: "".join(chr(0x61 + t % 26) for t in toks))
+        slot = w.open()
+        if via_body:
+            w.send_body(slot, body)
+        else:
+            assert w.send(slot, dsm.encode_in_msg("Audio", pcm=pcm24))
+            assert w.send(slot, dsm.encode_in_msg("Marker", id=0))
+            assert w.send(slot, dsm.encode_in_msg("Audio", pcm=np.zeros(240000, np.float32)))
+        msgs = []
+        for _ in range(400):
+            w.step()
+            got = w.recv(slot)
+            msgs += got
+            if any(m["type"] == "Marker" for m in got):
+                break
+        assert msgs[0] == {"type": "Ready"} and msgs[-1]["type"] == "Marker" or any(m["type"] == "Marker" for m in msgs)
+        assert sum(m["type"] == "Step" for m in msgs) >= len(pcm24) // 1920
+        outs.append(msgs)
+        w.close()
+    assert outs[0] == outs[1]
+    with pytest.raises(dsm.DsmError):
+        ora = orc.OracleAsr(cfg, B, *tiny_weights)
+        be, keep = worker_ref.oracle_backend(dsm, ora, cfg, B)
+        w = dsm.Worker(backend=be)
+        w.send_body(w.open(), b"not an audio file at all" * 10)
