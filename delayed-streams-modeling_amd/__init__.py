@@ -120,7 +120,7 @@ ABI_SYMBOLS = [
     "dsm_asr_step_pcm", "dsm_asr_poll_msgs", "dsm_asr_reset_slot", "dsm_mimi_reset_slot", "dsm_sync",
     "dsm_get_metrics", "dsm_batch_size", "dsm_n_q", "dsm_mimi_encode_step_dev", "dsm_asr_step_tokens_dev",
     "dsm_streams_join", "dsm_debug_read", "dsm_asr_step_pcm_dev", "dsm_prof_enable", "dsm_prof_read",
-    "dsm_debug_set_positions", "dsm_debug_set_text_tokens", "dsm_mimi_decode_step", "dsm_mimi_decode_step_dev",
+    "dsm_asr_create_replica", "dsm_debug_set_positions", "dsm_debug_set_text_tokens", "dsm_mimi_decode_step", "dsm_mimi_decode_step_dev",
     "dsm_lm_stream_groups", "dsm_debug_serialize_groups", "dsm_prof_read_device", "dsm_prof_timeline", "dsm_prof_timeline_read",
     "dsm_wav_decode", "dsm_mp3_decode", "dsm_mp3_decode_info", "dsm_mp3_probe", "dsm_resample", "dsm_pcm_decode",
     "dsm_mp3_test_synth", "dsm_mp3_test_tables", "dsm_mp3_test_imdct", "dsm_free", "dsm_linear_resampler_new", "dsm_linear_resampler_process",
@@ -183,6 +183,8 @@ def load_library(path=None):
     lib.dsm_mimi_decode_step_dev.restype = C.c_int
     lib.dsm_debug_set_positions.argtypes = [vp, C.c_uint32, C.c_uint32]
     lib.dsm_debug_set_positions.restype = C.c_int
+    lib.dsm_asr_create_replica.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
+    lib.dsm_asr_create_replica.restype = C.c_int
     lib.dsm_debug_set_text_tokens.argtypes = [vp, vp]
     lib.dsm_debug_set_text_tokens.restype = C.c_int
     lib.dsm_prof_enable.argtypes = [vp, C.c_uint]
@@ -664,6 +666,23 @@ class AsrEngine:
             raise DsmError(f"dsm_asr_create failed ({rc}): {msg.decode() if msg else '?'}")
         self.h = h
         self.n_q = self.lib.dsm_n_q(h)
+
+    @classmethod
+    def replica(cls, src, device_id, batch_size=None, cfg=None):
+        """A second engine in THIS process on `device_id` whose weights are a device-to-device copy of `src`'s arena
+        (dsm_asr_create_replica: hipMemcpyPeerAsync over xGMI; a device copy when device_id is src's own device)."""
+        self = cls.__new__(cls)
+        self.lib = src.lib
+        self.cfg = cfg if cfg is not None else src.cfg
+        self.B = batch_size if batch_size is not None else src.B
+        h = C.c_void_p()
+        rc = self.lib.dsm_asr_create_replica(src.h, C.byref(self.cfg) if cfg is not None else None, device_id, self.B, C.byref(h))
+        if rc != 0:
+            msg = self.lib.dsm_last_error(None)
+            raise DsmError(f"dsm_asr_create_replica failed ({rc}): {msg.decode() if msg else '?'}")
+        self.h = h
+        self.n_q = self.lib.dsm_n_q(h)
+        return self
 
     def weight_arena(self):
         """(device pointer, nbytes, manifest bytes) of this engine's packed weight arena (dsm_asr_weight_arena)."""

@@ -108,3 +108,29 @@ def fan_out_engine(dsm, cfg, batch_size, lm_path, mimi_path, dist, device, src=0
 
 def digest(raw):
     return hashlib.sha256(np.ascontiguousarray(raw).tobytes()).hexdigest()
+
+
+class WorkerRouter:
+    """One process, several GPUs: one engine + one worker per device, a new socket goes to the FIRST worker with a free slot —
+    `BatchedAsr::channels` (srv/batched_asr.rs:796-808: the first `None` of the slot table, "Server at capacity" when there is
+    none) across workers.  Stream ids are (worker index, slot); slots never migrate (a stream's ring caches live on one device).
+    Pure host logic: `workers` are dsm_amd.Worker objects (or anything with open / close_channel that raises at capacity)."""
+
+    def __init__(self, workers):
+        self.workers = list(workers)
+
+    def open(self):
+        for i, w in enumerate(self.workers):
+            try:
+                return i, w.open()
+            except Exception as ex:  # this worker is full: try the next device
+                if "capacity" not in str(ex):
+                    raise
+        raise RuntimeError("Server at capacity")
+
+    def close(self, stream):
+        i, slot = stream
+        self.workers[i].close_channel(slot)
+
+    def worker_of(self, stream):
+        return self.workers[stream[0]]

@@ -162,6 +162,11 @@ const char* dsm_last_error(const dsm_engine*); /* NULL engine -> last create err
 int dsm_asr_weight_arena(dsm_engine*, void** d_arena, size_t* arena_bytes, const uint8_t** manifest, size_t* manifest_bytes);
 int dsm_asr_create_from_arena(const dsm_asr_config* cfg, int device_id, int batch_size, const void* d_arena,
                               size_t arena_bytes, const uint8_t* manifest, size_t manifest_bytes, dsm_engine** out);
+/* r04 — one process, several devices (the reference is one process: srv/main.rs:317-327): a second engine on `device_id` whose
+ * weights are a device-to-device copy of `src`'s arena (hipMemcpyPeerAsync over xGMI in 256 MB pieces; a plain device copy when
+ * device_id is src's own device).  The replica owns its copy; `cfg` NULL = src's configuration.  INTEGRATION.md shows the Rust
+ * server creating one engine + one worker per GPU this way and routing a new socket to the first worker with a free slot. */
+int dsm_asr_create_replica(dsm_engine* src, const dsm_asr_config* cfg, int device_id, int batch_size, dsm_engine** out);
 
 /*
  * Mimi::encode_step(&StreamTensor, &StreamMask) — core/mimi.rs:195-206, called at

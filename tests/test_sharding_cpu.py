@@ -78,3 +78,27 @@ def test_two_rank_broadcast_and_shard_independence(dsm, orc, tiny_weights, tmp_p
         for r in res:
             lo, hi = r["lo"], r["hi"]
             assert codes[lo:hi].tolist() == r["out"][s][0] and text[lo:hi].tolist() == r["out"][s][1]
+
+
+def test_router_sends_a_new_socket_to_the_first_worker_with_a_free_slot():
+    """BatchedAsr::channels across workers (srv/batched_asr.rs:796-808), the host half of the one-process multi-GPU layout."""
+    import pytest
+    from dsm_amd.sharding import WorkerRouter
+
+    class FakeWorker:
+        def __init__(self, B):
+            self.free = list(range(B))
+        def open(self):
+            if not self.free:
+                raise RuntimeError("Server at capacity")
+            return self.free.pop(0)
+        def close_channel(self, slot):
+            self.free.append(slot); self.free.sort()
+
+    r = WorkerRouter([FakeWorker(2), FakeWorker(1), FakeWorker(2)])
+    got = [r.open() for _ in range(5)]
+    assert got == [(0, 0), (0, 1), (1, 0), (2, 0), (2, 1)]
+    with pytest.raises(RuntimeError, match="Server at capacity"):
+        r.open()
+    r.close((1, 0)); r.close((0, 1))
+    assert r.open() == (0, 1) and r.open() == (1, 0)  # the first free slot of the first worker that has one

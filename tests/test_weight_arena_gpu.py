@@ -95,3 +95,35 @@ def test_fan_out_engine_under_the_launcher(gpu, dsm, lib, tiny_weights, tmp_path
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["same"] is True and out["stats"]["ranks"] == 1 and out["stats"]["arena_bytes"] > 0
+
+
+def test_replica_in_one_process_same_bits_and_owns_its_arena(gpu, dsm, lib):
+    """dsm_asr_create_replica (r04: the one-process multi-device load behind the C ABI).  On the one-GPU box the replica lands on the
+    source's own device (the copy is then a device-to-device memcpy instead of hipMemcpyPeerAsync; everything after it is the same
+    code): a different batch size, the source destroyed FIRST (the replica owns its copy), and the same bits as the source for the
+    same streams."""
+    import numpy as np
+    from dsm_amd import synth
+    cfg = dsm.config_tiny()
+    lm, mimi = synth.make_synth_weights(cfg, os.environ.get("DSM_WEIGHTS_DIR", "/tmp/dsm_weights"), tag="tiny")
+    src = dsm.AsrEngine(cfg, 3, lm, mimi)
+    rep = dsm.AsrEngine.replica(src, 0, batch_size=5)
+    assert rep.weight_arena()[0] != src.weight_arena()[0] and rep.weight_arena()[1] == src.weight_arena()[1]
+    pcm = synth.synth_pcm(5, 6)
+    want = []
+    for s in range(6):
+        want.append(src.step_pcm(pcm[s][:3], np.ones(3, np.uint8)))
+    src.close()  # the replica must not depend on the source's memory
+    for s in range(6):
+        c, t, p = rep.step_pcm(pcm[s], np.ones(5, np.uint8))
+        assert np.array_equal(c[:3], want[s][0]) and np.array_equal(t[:3], want[s][1])
+        assert np.array_equal(p[:, :3].view(np.uint32), want[s][2].view(np.uint32))
+    rep2 = dsm.AsrEngine.replica(rep, 0)  # a replica of a replica
+    assert rep2.B == 5
+    rep2.close(); rep.close()
+    with pytest.raises(dsm.DsmError, match="no such device"):
+        e = dsm.AsrEngine(cfg, 1, lm, mimi)
+        try:
+            dsm.AsrEngine.replica(e, 63)
+        finally:
+            e.close()
