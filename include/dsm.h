@@ -514,6 +514,9 @@ int dsm_worker_buffered(dsm_worker*, int slot);        /* samples waiting in the
  * decoded and queued like InMsg::Audio (:941-947); a decode error is reported and skipped like the reference logs it.
  * Without one, dsm_worker_send keeps refusing OggOpus messages (DSM_ERR_STATE). */
 typedef int (*dsm_opus_decode_fn)(void* user, int slot, const uint8_t* packet, size_t len, float* pcm_out, size_t cap);
+/* Threading contract of the decoder callback: it is called from the thread that called dsm_worker_send, OUTSIDE
+ * the worker lock and under the CHANNEL's own lock only — concurrently for different slots, never concurrently for one slot;
+ * `slot` tells the callback which per-socket decoder state to use.  It must not call back into dsm_worker_* for the same slot. */
 void dsm_worker_set_opus_decoder(dsm_worker*, dsm_opus_decode_fn, void* user);
 
 #ifdef __cplusplus

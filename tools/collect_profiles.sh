@@ -12,7 +12,7 @@ cp $P/pmc_hbm_traffic.json $P/pmc_mfma_b64.json $P/pmc_mfma_b1024.json $D/
 # rocprofv3 writes one directory per traced process: keep the kernel-stats table of the one that ran the bench (the largest)
 for t in trace_1stream:kernel_stats_single_stream trace:kernel_stats_overlapped; do
   src=${t%%:*}; dst=${t##*:}
-  f=$(ls -S $P/$src/*/*_kernel_stats.csv | head -1)  # the bench process itself (its host-path legs are traced as child processes too: smaller tables)
+  f=$(ls -t $P/$src/*/*_kernel_stats.csv | head -1)  # tools/gpu_round.sh wipes the trace directories at the start of a visit and traces no child legs: the newest table is this visit's
   cp "$f" $D/$dst.csv
   grep '^{' $P/${src}_bench.json > $D/$dst.bench.json || true
 done
