@@ -61,6 +61,9 @@ static void launch_old(const Shape& sh, const Bufs& b, int M, int buf, hipStream
     a.w_ntiles = (sh.N * (EPI == EPI_GATE ? 2 : 1)) / 16;
     if (MT == 4) { if (form == 3) hipLaunchKernelGGL((gemm_bx3u_kernel<float, 4, NT, EPI, 4, 1>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((gemm_bx3u_kernel<float, 4, NT, EPI, 4, 2>), grid, dim3(256), 0, st, a); }
     else { if (form == 3) hipLaunchKernelGGL((gemm_bx3u_kernel<float, 2, NT, EPI, 8, 1>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((gemm_bx3u_kernel<float, 2, NT, EPI, 8, 2>), grid, dim3(256), 0, st, a); }
+  } else if (bx3 && form == 5) {  // M = 64 as two 32-row z-tiles of the MT = 2 kernel (weights read twice: the second time from L2 / MALL)
+    dim3 g2(gx, chunks, (M + 31) / 32);
+    hipLaunchKernelGGL((gemm_bx3u_kernel<float, 2, NT, EPI, 8>), g2, dim3(256), 0, st, a);
   } else if (bx3 && form == 2) {
     if (MT == 4) hipLaunchKernelGGL((gemm_bx3u_kernel<float, 4, NT, EPI, 4>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((gemm_bx3u_kernel<float, 2, NT, EPI, 4>), grid, dim3(256), 0, st, a);
@@ -174,13 +177,14 @@ static void run_shape(const Shape& sh, int M, hipStream_t st) {
   const double told = time_us(old, reps, NBUF, st);
   old(0);
   CK(hipStreamSynchronize(st));
-  if (BX3) for (int form = 1; form <= 4; ++form) {
+  if (BX3) for (int form = 1; form <= 5; ++form) {
+    if (form == 5 && M <= 32) continue;
     CK(hipMemset(b.Ynew, 0xFF, (size_t)M * sh.N * 4));
     oldf(0, form);
     CK(hipStreamSynchronize(st)); CK(hipGetLastError());
     const size_t bad = compare(b.Yold, b.Ynew, (size_t)M * sh.N);
     const double t = time_us([&](int buf) { oldf(buf, form); }, reps, NBUF, st);
-    printf("  bx3u form %d (1: HB 8|4, 2: HB 4, 3: tile-major W, 4: chunk-major W) + reduce : %7.2f us  mismatches %zu\n", form, t, bad);
+    printf("  bx3u form %d (1: HB 8|4, 2: HB 4, 3: tile-major W, 4: chunk-major W, 5: two MT=2 z-tiles) + reduce : %7.2f us  mismatches %zu\n", form, t, bad);
   }
   if (g_skip_wk) printf("  (wk variants skipped)\n");
   printf("  old split-K + reduce%s            : %7.2f us\n", sh.epi == EPI_STORE ? "+norm" : "     ", told);
