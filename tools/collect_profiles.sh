@@ -24,6 +24,12 @@ if [ -d $P/trace_tts ]; then
   grep '^{' $P/trace_tts_bench.json > $D/tts_kernel_stats.bench.json || true
   python3 tools/trace_table.py $P/trace_tts > $D/tts_kernel_trace_summary.txt
 fi
+if [ -d $P/trace_26b ]; then
+  f=$(ls -t $P/trace_26b/*/*_kernel_stats.csv | head -1)
+  cp "$f" $D/kernel_stats_stt_2.6b_single_stream.csv
+  grep '^{' $P/trace_26b_bench.json > $D/kernel_stats_stt_2.6b_single_stream.bench.json || true
+  cp $P/kernel_trace_stt_2.6b_summary.txt $P/pmc_hbm_traffic_stt_2.6b.json $D/
+fi
 if [ -d $P/extra ]; then
   mkdir -p $D/extra
   for f in $P/extra/*.json; do grep '^{' "$f" > $D/extra/$(basename "$f") || true; done
