@@ -46,6 +46,7 @@ struct Linear {  // packed weight [Npad][Kpad] (+ optional bias) on the device
   float* bias = nullptr;
   int N = 0, K = 0, Npad = 0, Kpad = 0;
   bool bf16 = false;
+  bool packed = false;  // bf16 only (r04): fragment-major [Npad / 16][Kpad / 32][64 lanes][8] instead of row-major (dsm_wbase)
 };
 
 struct ConvGeom {
@@ -522,7 +523,15 @@ struct Loader {
 int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // pack [N][K] f32 row-major into the GEMM layout [Npad][Kpad] (zero padded)
-int pack_linear(dsm_engine* e, Linear* L, const float* w, int N, int K, bool bf16, const float* bias) {
+// bf16 weights (the LM's) are stored FRAGMENT-MAJOR since r04: the 16 rows x 32 k block that one wave loads as its MFMA A operand
+// (lane (r, q) = 8 consecutive k of row r) is 1 KB contiguous, tile (n / 16, k / 32) at ((n / 16) * (Kpad / 32) + k / 32) * 512
+// elements, lane q * 16 + r inside it — every weight load instruction covers eight full 128-byte lines instead of sixteen half
+// lines 4 KB apart, and a wave's chunk is 8 KB of one DRAM page run (experiments/gemm_wk_probe: QKV / gate launches -10 %).
+// split_row: a row offset the kernels address as a tile origin (the gate's up half at +hidden): must be a multiple of 16, else
+// the matrix stays row-major.  DSM_WPACK=0: row-major everywhere.
+int pack_linear(dsm_engine* e, Linear* L, const float* w, int N, int K, bool bf16, const float* bias, int split_row = 0) {
+  static const bool wpack = !(getenv("DSM_WPACK") && atoi(getenv("DSM_WPACK")) == 0);
+  L->packed = bf16 && wpack && (split_row % 16 == 0);
   L->N = N;
   L->K = K;
   L->Npad = round_up(N, 64) + 64;  // the tiled kernel reads whole 64-row tiles (and the gate's up-tile at +hidden)
@@ -532,9 +541,15 @@ int pack_linear(dsm_engine* e, Linear* L, const float* w, int N, int K, bool bf1
   const bool skip = e->skip_host_weights();
   if (bf16) {
     std::vector<uint16_t> p(skip ? 0 : n, 0);
-    if (!skip)
+    if (!skip) {
+      const size_t nblk = (size_t)L->Kpad >> 5;
       for (int i = 0; i < N; ++i)
-        for (int j = 0; j < K; ++j) p[(size_t)i * L->Kpad + j] = dsm_f32_to_bf16(w[(size_t)i * K + j]);
+        for (int j = 0; j < K; ++j) {
+          const size_t at = L->packed ? ((((size_t)i >> 4) * nblk + ((size_t)j >> 5)) * 64 + (size_t)(((j >> 3) & 3) * 16 + (i & 15))) * 8 + (j & 7)
+                                      : (size_t)i * L->Kpad + j;
+          p[at] = dsm_f32_to_bf16(w[(size_t)i * K + j]);
+        }
+    }
     uint16_t* d = nullptr;
     if (int rc = e->upload_w(&d, p.data(), n)) return rc;
     L->w = d;
@@ -640,7 +655,7 @@ int load_transformer(dsm_engine* e, Loader& ld, TransformerW* t, const dsm_trans
     if (cfg.gating) {
       auto wi = ld.get((int64_t)2 * t->hidden * d, "%s.layers.%d.gating.linear_in.weight", prefix, l);
       if (ld.failed) return DSM_ERR_IO;
-      if (int rc = pack_linear(e, &L.ff_in, wi.data(), 2 * t->hidden, d, bf16, nullptr)) return rc;
+      if (int rc = pack_linear(e, &L.ff_in, wi.data(), 2 * t->hidden, d, bf16, nullptr, t->hidden)) return rc;
       auto wo = ld.get((int64_t)d * t->hidden, "%s.layers.%d.gating.linear_out.weight", prefix, l);
       if (ld.failed) return DSM_ERR_IO;
       if (int rc = pack_linear(e, &L.ff_out, wo.data(), d, t->hidden, bf16, nullptr)) return rc;
@@ -1196,6 +1211,7 @@ GemmArgs base_args(const Linear& L, const float* X, RowMap xmap, int M) {
   a.X = X;
   a.xmap = xmap;
   a.W = L.w;
+  a.wpacked = L.packed ? 1 : 0;
   a.Kpad = L.Kpad;
   a.K = L.K;
   a.N = L.N;

@@ -65,8 +65,9 @@ __global__ __launch_bounds__(64 * NW, OCC) void gemm_wk_kernel(GemmArgs a) {
   f32x4 acc[NT][MT];
   if (nkb > 0) {
     const uint16_t* wrow[NT];
+    const int wst = dsm_wstep<uint16_t>(a);
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) wrow[nt] = W + (long)(n_base + nt * a.nt_stride + r) * a.Kpad + 8 * q + 32 * kb0;
+    for (int nt = 0; nt < NT; ++nt) wrow[nt] = dsm_wbase<uint16_t>(a, W, n_base + nt * a.nt_stride, r, q) + (long)32 * kb0 * wst;
     const float* xrow[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void gemm_wk_kernel(GemmArgs a) {
     for (int i = 0; i < NB; ++i) {
       const int kb = 32 * (i < nkb ? i : nkb - 1);
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) wv[i][nt] = *reinterpret_cast<const uint4*>(wrow[nt] + kb);
+      for (int nt = 0; nt < NT; ++nt) wv[i][nt] = *reinterpret_cast<const uint4*>(wrow[nt] + (long)kb * wst);
     }
     __builtin_amdgcn_sched_barrier(0);  // every request is out before the first block waits for its own
 #pragma unroll
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bx3u_kernel(GemmArgs a) {
     for (int nt = 0; nt < NT; ++nt) {
       const int gc = g < nkb ? g : nkb - 1;
       if (WL == 0)
-        wv[g][nt] = *reinterpret_cast<const uint4*>(W + (long)(n_base + nt * a.nt_stride + r) * a.Kpad + 8 * q + kb);
+        wv[g][nt] = *reinterpret_cast<const uint4*>(dsm_wbase<uint16_t>(a, W, n_base + nt * a.nt_stride, r, q) + (long)kb * dsm_wstep<uint16_t>(a));
       else if (WL == 1)
         wv[g][nt] = *reinterpret_cast<const uint4*>(W + ((long)((n_base + nt * a.nt_stride) >> 4) * (a.Kpad >> 5) + kb0 + gc) * 512 + lane * 8);
       else
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wkn_kernel(GemmArgs a) {
       const int kb = 32 * (i < nkb ? i : nkb - 1);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
-        wv[i][nt] = *reinterpret_cast<const uint4*>(W + (long)(n_base + nt * a.nt_stride + r) * a.Kpad + 8 * q + 32 * kb0 + kb);
+        wv[i][nt] = *reinterpret_cast<const uint4*>(dsm_wbase<uint16_t>(a, W, n_base + nt * a.nt_stride, r, q) + (long)(32 * kb0 + kb) * dsm_wstep<uint16_t>(a));
     }
   }
   __builtin_amdgcn_sched_barrier(0);

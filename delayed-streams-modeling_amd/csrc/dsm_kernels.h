@@ -45,7 +45,8 @@ struct GemmArgs {
   const void* W;  // packed [Npad][Kpad], K zero-padded to a multiple of 32, rows to a multiple of 16
   int Kpad, K, N, M;
   int nt_stride;  // row distance between the NT n-tiles of one wave (16, or `hidden` for the gate)
-  int w_ntiles;   // 16-row tiles of W in all (packed weight layouts, dsm_gemm_wk.h)
+  int wpacked;    // bf16 W is fragment-major [N / 16][Kpad / 32][64][8] (pack_linear, r04) instead of row-major [N][Kpad]
+  int w_ntiles;   // 16-row tiles of W in all (chunk-major experiment, dsm_gemm_wk.h)
   int wg_cols;    // weight rows per workgroup (0 = 64).  128 with nt_stride 64: gemm_bx3_kernel's two-n-tile form for plain
                   // epilogues — wave w owns columns 16w.. and 64 + 16w.. of the workgroup's 128
   // EPI_STORE
@@ -90,6 +91,16 @@ struct GemmArgs {
   // optional device-clock bracket of the launch (timeline diagnostics, dsm_prof_timeline): {first workgroup in, last out}
   unsigned long long* ts;
 };
+
+// Where lane (r, q) finds its 8 consecutive k of weight row n0 + r in the first 32-wide block, and how far apart blocks are
+// (elements): row-major, or — bf16 weights since r04 — fragment-major (pack_linear).  n0 is a multiple of 16.
+template <typename WT>
+__device__ __forceinline__ const WT* dsm_wbase(const GemmArgs& a, const WT* W, int n0, int r, int q) {
+  if (sizeof(WT) == 2 && a.wpacked) return W + ((long)(n0 >> 4) * (a.Kpad >> 5)) * 512 + (q * 16 + r) * 8;
+  return W + (long)(n0 + r) * a.Kpad + 8 * q;
+}
+template <typename WT>
+__device__ __forceinline__ int dsm_wstep(const GemmArgs& a) { return (sizeof(WT) == 2 && a.wpacked) ? 16 : 1; }  // x k (multiples of 32)
 
 // first / last workgroups of a launch stamp the wall clock (dispatch is in index order; a few hundred atomics at most)
 __device__ __forceinline__ void launch_stamp_begin(unsigned long long* ts) {
@@ -300,7 +311,8 @@ __global__ void gemm_mfma_kernel(GemmArgs a) {
 
   const WT* wrow[NT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) wrow[nt] = W + (long)(n_base + nt * a.nt_stride + r) * a.Kpad + 8 * q;
+  for (int nt = 0; nt < NT; ++nt) wrow[nt] = dsm_wbase<WT>(a, W, n_base + nt * a.nt_stride, r, q);
+  const int wst = dsm_wstep<WT>(a);
   const float* xrow[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -321,7 +333,7 @@ __global__ void gemm_mfma_kernel(GemmArgs a) {
     for (int kb = k0; kb < k1; kb += 32) {
       float wa[NT][8], xb[MT][8];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) load_w8<WT>(wrow[nt] + kb, wa[nt]);
+      for (int nt = 0; nt < NT; ++nt) load_w8<WT>(wrow[nt] + (long)kb * wst, wa[nt]);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         if (XALIGNED) {
@@ -436,7 +448,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs a) {
 
   const WT* wrow[NT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) wrow[nt] = W + (long)(n_base + nt * a.nt_stride + r) * a.Kpad + 8 * q;
+  for (int nt = 0; nt < NT; ++nt) wrow[nt] = dsm_wbase<WT>(a, W, n_base + nt * a.nt_stride, r, q);
+  const int wst = dsm_wstep<WT>(a);
   // cooperative X fetch: 16*MT rows x 8 float4 pieces; thread t takes piece t (and t+256 when MT == 4).
   // Scalars, not arrays: small per-thread arrays ended up in scratch memory here.
   constexpr int PIECES = 16 * MT * 8;
@@ -480,7 +493,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs a) {
     const int kb_ = k0 + 32 * ((I) < nkb ? (I) : nkb - 1);                             \
     xp##I = *reinterpret_cast<const float4*>(xsrc0 + kb_);                             \
     xq##I = TWO ? *reinterpret_cast<const float4*>(xsrc1 + kb_) : xp##I;               \
-    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) rw##I[nt].load(wrow[nt] + kb_);  \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) rw##I[nt].load(wrow[nt] + (long)kb_ * wst);  \
   }
   DSM_FOR8(DSM_LOADBLK)
   __builtin_amdgcn_sched_barrier(0);  // all requests issued before the first block waits for its own
@@ -617,7 +630,8 @@ __global__ __launch_bounds__(256, OCC) void gemm_loop_kernel(GemmArgs a) {
   const WT* W = reinterpret_cast<const WT*>(a.W);
   const WT* wrow[NT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) wrow[nt] = W + (long)(n_base + nt * a.nt_stride + r) * a.Kpad + 8 * q;
+  for (int nt = 0; nt < NT; ++nt) wrow[nt] = dsm_wbase<WT>(a, W, n_base + nt * a.nt_stride, r, q);
+  const int wst = dsm_wstep<WT>(a);
   constexpr int PIECES = 16 * MT * 8;
   constexpr bool TWO = PIECES > 256;
   const bool has0 = tid < PIECES;
@@ -648,7 +662,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_loop_kernel(GemmArgs a) {
     const int kb_ = 32 * min((G), nb - 1);                                           \
     xp##S = *reinterpret_cast<const float4*>(xsrc0 + kb_);                           \
     xq##S = TWO ? *reinterpret_cast<const float4*>(xsrc1 + kb_) : xp##S;             \
-    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) rw##S[nt].load(wrow[nt] + kb_); \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) rw##S[nt].load(wrow[nt] + (long)kb_ * wst); \
   }
   DSM_LLOAD(0, 0) DSM_LLOAD(1, 1)
   if (D == 4) { DSM_LLOAD(2, 2) DSM_LLOAD(3, 3) }
@@ -765,7 +779,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bx3_kernel(GemmArgs a) {
   const uint16_t* W = reinterpret_cast<const uint16_t*>(a.W);
   const uint16_t* wrow[NT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) wrow[nt] = W + (long)(n_base + nt * a.nt_stride + r) * a.Kpad + 8 * q;
+  for (int nt = 0; nt < NT; ++nt) wrow[nt] = dsm_wbase<uint16_t>(a, W, n_base + nt * a.nt_stride, r, q);
+  const int wst = dsm_wstep<uint16_t>(a);
   constexpr int PIECES = 16 * MT * 8;
   constexpr bool TWO = PIECES > 256;
   const bool has0 = tid < PIECES;
@@ -800,7 +815,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bx3_kernel(GemmArgs a) {
   float4 xb = TWO ? *reinterpret_cast<const float4*>(xsrc1 + 32 * kb0) : xa;
   uint4 wv[NT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) wv[nt] = *reinterpret_cast<const uint4*>(wrow[nt] + 32 * kb0);
+  for (int nt = 0; nt < NT; ++nt) wv[nt] = *reinterpret_cast<const uint4*>(wrow[nt] + (long)32 * kb0 * wst);
   for (int g = kb0; g < kb1; ++g) {
     const int buf = (g - kb0) & 1;
     if (has0) stage(buf, xa, row0);
@@ -817,7 +832,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bx3_kernel(GemmArgs a) {
       xa = *reinterpret_cast<const float4*>(xsrc0 + 32 * gn);
       if (TWO) xb = *reinterpret_cast<const float4*>(xsrc1 + 32 * gn);
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) wv[nt] = *reinterpret_cast<const uint4*>(wrow[nt] + 32 * gn);
+      for (int nt = 0; nt < NT; ++nt) wv[nt] = *reinterpret_cast<const uint4*>(wrow[nt] + (long)32 * gn * wst);
     }
     __syncthreads();  // block g's planes are complete; buffer buf ^ 1 was last read before the previous barrier
 #pragma unroll
