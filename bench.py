@@ -43,7 +43,7 @@ def parse():
                          "mode's step time is reported beside the headline as `other_dot_mode`")
     ap.add_argument("--spawn-check-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)      # tests: this rank raises mid-run
     ap.add_argument("--spawn-check-arena-skew-rank", type=int, default=-1, help=argparse.SUPPRESS)  # tests: this rank reports another arena size
-    ap.add_argument("--host-path-legs", default="400,2048,2304",
+    ap.add_argument("--host-path-legs", default="400,2048,2560",
                     help="batch sizes for the end-to-end host-path legs (tools/host_path_bench: msgpack in, worker threads, H2D, "
                          "msgpack out); empty = skip")
     ap.add_argument("--host-path-frames", type=int, default=16)
@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true", help="single-stream step_pcm instead of the encoder/model stream pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=4, help="oracle frames timed for cpu_baseline (a full-ring frame of 64 streams takes a few seconds on 16 cores)")
-    ap.add_argument("--capacity-legs", default="400,2048,2176,2304",
+    ap.add_argument("--capacity-legs", default="400,2048,2304,2560,2688",
                     help="comma-separated larger batches timed after the headline run (N = 1 only; '' to skip)")
     ap.add_argument("--part", default="all", choices=["all", "lm", "enc"],
                     help="experiment: time only the LM step (codes fed from a fixed device buffer) or only the Mimi encode")

@@ -238,6 +238,11 @@ struct dsm_engine {
   hipEvent_t ev_join = nullptr, ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;
   MimiW mimi_w;
   MimiState mimi[2];
+  // mimi[1] — the Mimi clone of asr::State (core/asr.rs:58), used only by dsm_asr_step_pcm[_dev] — is allocated on first use
+  // (r04): a server drives the encoder-thread clone (mimi[0]) and step_tokens, and at the capacity batch the second state set is
+  // 11 GB of HBM that 256 more streams' ring caches fit into
+  std::atomic<bool> mimi1_ready{false};
+  std::mutex mimi1_mu;
   MimiDecState dec;
   float* h_pcm_out = nullptr;
   LmW lm_w;
