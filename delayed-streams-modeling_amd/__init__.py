@@ -120,7 +120,7 @@ ABI_SYMBOLS = [
     "dsm_asr_step_pcm", "dsm_asr_poll_msgs", "dsm_asr_reset_slot", "dsm_mimi_reset_slot", "dsm_sync",
     "dsm_get_metrics", "dsm_batch_size", "dsm_n_q", "dsm_mimi_encode_step_dev", "dsm_asr_step_tokens_dev",
     "dsm_streams_join", "dsm_debug_read", "dsm_asr_step_pcm_dev", "dsm_prof_enable", "dsm_prof_read",
-    "dsm_asr_create_replica", "dsm_debug_set_positions", "dsm_debug_set_text_tokens", "dsm_mimi_decode_step", "dsm_mimi_decode_step_dev",
+    "dsm_asr_create_replica", "dsm_asr_set_seed", "dsm_debug_set_positions", "dsm_debug_set_text_tokens", "dsm_mimi_decode_step", "dsm_mimi_decode_step_dev",
     "dsm_lm_stream_groups", "dsm_debug_serialize_groups", "dsm_prof_read_device", "dsm_prof_timeline", "dsm_prof_timeline_read",
     "dsm_wav_decode", "dsm_mp3_decode", "dsm_mp3_decode_info", "dsm_mp3_probe", "dsm_resample", "dsm_pcm_decode",
     "dsm_mp3_test_synth", "dsm_mp3_test_tables", "dsm_mp3_test_imdct", "dsm_free", "dsm_linear_resampler_new", "dsm_linear_resampler_process",
@@ -185,6 +185,8 @@ def load_library(path=None):
     lib.dsm_debug_set_positions.restype = C.c_int
     lib.dsm_asr_create_replica.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
     lib.dsm_asr_create_replica.restype = C.c_int
+    lib.dsm_asr_set_seed.argtypes = [vp, C.c_int, C.c_uint64]
+    lib.dsm_asr_set_seed.restype = C.c_int
     lib.dsm_debug_set_text_tokens.argtypes = [vp, vp]
     lib.dsm_debug_set_text_tokens.restype = C.c_int
     lib.dsm_prof_enable.argtypes = [vp, C.c_uint]
@@ -798,6 +800,10 @@ class AsrEngine:
 
     def debug_set_positions(self, lm_pos, mimi_pos):
         self._check(self.lib.dsm_debug_set_positions(self.h, lm_pos, mimi_pos))
+
+    def set_seed(self, slot, seed):
+        """temperature > 0: restart the slot's Gumbel-noise stream (ChaCha12 keyed by seed_from_u64(seed))."""
+        self._check(self.lib.dsm_asr_set_seed(self.h, slot, seed))
 
     def debug_set_text_tokens(self, tokens):
         """Teacher forcing: the text token every slot feeds back into its next step."""

@@ -178,6 +178,8 @@ struct LmState {
         *eh = nullptr, *prs = nullptr;
   uint32_t *next_cb = nullptr, *text_token = nullptr, *text_out = nullptr, *codes_in = nullptr;
   uint8_t *first_step = nullptr, *mask = nullptr;
+  uint32_t* rng_key = nullptr;             // [B][8] ChaCha12 key per slot (temperature > 0: lm_gumbel_kernel; dsm_asr_set_seed)
+  unsigned long long* rng_pos = nullptr;   // [B] words drawn so far (multiples of 16)
   uint8_t* gmask = nullptr;  // per-group private copy of the step's mask (groups free-run against each other)
   TransformerState tr;
   // stream groups: slots [b0, b0+nb) of group g step on their own HIP stream so that one group's HBM-bound attention

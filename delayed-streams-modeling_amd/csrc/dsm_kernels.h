@@ -1447,6 +1447,58 @@ __global__ void lm_argmax_kernel(const float* __restrict__ logits, int V, uint32
   }
 }
 
+// temperature > 0 (r04): candle_nn::sampling::gumbel_softmax of the text logits — core/asr.rs:211-215, dsm_sampling.h
+// dsm_gumbel_value — with one seeded ChaCha12 stream per slot: entry j of the step takes word pos + j (pos a multiple of 16: a
+// thread produces whole blocks), argmax with first occurrence on ties; an active slot's stream advances by V rounded up to 16.
+__global__ void lm_gumbel_kernel(const float* __restrict__ logits, int V, float temperature, const uint32_t* __restrict__ rng_key,
+                                 unsigned long long* __restrict__ rng_pos, uint32_t* __restrict__ text_out,
+                                 uint32_t* __restrict__ text_token, uint8_t* __restrict__ first_step,
+                                 const uint8_t* __restrict__ active) {
+  const int b = blockIdx.x;
+  const float* lg = logits + (long)b * V;
+  uint32_t key[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) key[i] = rng_key[b * 8 + i];
+  const unsigned long long pos = rng_pos[b];
+  float bv = -DSM_INF_F;
+  int bi = 0x7FFFFFFF;
+  const int nblk = (V + 15) >> 4;
+  for (int blk = threadIdx.x; blk < nblk; blk += blockDim.x) {
+    uint32_t w[16];
+    dsm_chacha_block(key, (pos >> 4) + (unsigned long long)blk, 12, w);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int j = 16 * blk + i;
+      if (j < V) {
+        const float v = dsm_gumbel_value(lg[j], w[i], temperature);
+        if (v > bv || (v == bv && j < bi)) { bv = v; bi = j; }
+      }
+    }
+  }
+  __shared__ float sv[256];
+  __shared__ int si[256];
+  sv[threadIdx.x] = bv;
+  si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int off = blockDim.x / 2; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      const float ov = sv[threadIdx.x + off];
+      const int oi = si[threadIdx.x + off];
+      if (ov > sv[threadIdx.x] || (ov == sv[threadIdx.x] && oi < si[threadIdx.x])) { sv[threadIdx.x] = ov; si[threadIdx.x] = oi; }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const uint32_t tok = si[0] == 0x7FFFFFFF ? 0u : (uint32_t)si[0];
+    text_out[b] = tok;
+    if (active[b]) {
+      text_token[b] = tok;
+      first_step[b] = 0;
+      rng_pos[b] = pos + 16ull * (unsigned long long)nblk;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // TTS glue — core/tts_streaming.rs:117-242, core/lm.rs:640-684, :983-995
 // ------------------------------------------------------------------------------------------

@@ -90,6 +90,35 @@ DSM_HD float dsm_expf(float x) {
   return (y * s1) * s2;
 }
 
+/* ln(x) for finite x > 0 (normal or subnormal), < 1 ulp: x = 2^e m with m in [sqrt(1/2), sqrt(2)), f = m - 1, s = f / (2 + f),
+ * ln(1 + f) = f - f^2/2 + s (f^2/2 + R(s^2)) with R the degree-4 minimax polynomial in s^2 that fdlibm's logf publishes
+ * (Lg1..Lg4).  IEEE +, -, *, / only, in a fixed order: the same bits from gcc and hipcc (r04: the Gumbel noise of
+ * candle_nn::sampling::gumbel_softmax, core/asr.rs:211-215). */
+DSM_HD float dsm_logf(float x) {
+  uint32_t ix = dsm_f32_as_u32(x);
+  int k = 0;
+  if (ix < 0x00800000u) { /* subnormal: scale up by 2^25 */
+    x = x * 33554432.0f;
+    ix = dsm_f32_as_u32(x);
+    k = -25;
+  }
+  k += (int)(ix >> 23) - 127;
+  ix &= 0x007FFFFFu;
+  const uint32_t i = (ix + (0x95f64u << 3)) & 0x800000u; /* m >= sqrt(2): halve it */
+  const float m = dsm_u32_as_f32(ix | (i ^ 0x3F800000u));
+  k += (int)(i >> 23);
+  const float f = m - 1.0f;
+  const float s = f / (2.0f + f);
+  const float dk = (float)k;
+  const float z = s * s;
+  const float w = z * z;
+  const float t1 = w * (0.40000972152f + w * 0.24279078841f);
+  const float t2 = z * (0.66666662693f + w * 0.28498786688f);
+  const float R = t2 + t1;
+  const float hfsq = (0.5f * f) * f;
+  return dk * 6.9313812256e-01f - ((hfsq - (s * (hfsq + R) + dk * 9.0580006145e-06f)) - f);
+}
+
 /* candle Activation::Elu(1.0):  x >= 0 ? x : exp(x) - 1 */
 DSM_HD float dsm_elu(float x) { return x >= 0.0f ? x : dsm_expf(x) - 1.0f; }
 

@@ -86,7 +86,8 @@ typedef struct dsm_asr_config {
   int extra_heads_num;   /* [modules.asr.model.extra_heads] num_heads (0 if absent) */
   int extra_heads_dim;
   int asr_delay_in_tokens;
-  float temperature;     /* only 0 (argmax) is on the accelerated path (core/asr.rs:208-216) */
+  float temperature;     /* <= 0: argmax; > 0 (r04): candle_nn::sampling::gumbel_softmax (core/asr.rs:211-215) with a seeded ChaCha12
+                            stream per slot (dsm_asr_set_seed) — the reference draws from an unseeded device generator: unpinnable */
   dsm_mimi_config mimi;
   /* engine numerics: 1 = K/V ring cache stored as bf16 (GPU target, BASELINE.md roofline),
    * 0 = f32 cache (the Candle CPU path's dtype, srv/utils.rs:386-395). */
@@ -228,6 +229,9 @@ int dsm_asr_poll_msgs(dsm_engine*, dsm_asr_msg* msgs, int cap, uint32_t* tokens_
  * behaviour change inside dsm_asr_reset_slot. */
 int dsm_asr_reset_slot(dsm_engine*, int slot);
 int dsm_mimi_reset_slot(dsm_engine*, int slot);
+/* temperature > 0 only: (re)start the slot's Gumbel-noise stream at word 0 of ChaCha12 keyed by rand's seed_from_u64(seed)
+ * (slot b starts with seed 0x5EED0000 + b).  A reset of the slot does not touch the stream, like the reference's global generator. */
+int dsm_asr_set_seed(dsm_engine*, int slot, uint64_t seed);
 
 /* Device::synchronize — srv/batched_asr.rs:238. */
 int dsm_sync(dsm_engine*);

@@ -1755,6 +1755,8 @@ struct orc_asr {
   orc_mimi* mimi[2]; /* [0] encoder-thread clone (srv/batched_asr.rs:297), [1] state.audio_tokenizer */
   orc_item* batch;
   uint32_t* next_codebooks; /* [B][codebooks] — core/asr.rs:61 */
+  uint32_t* rng_key;        /* [B][8] ChaCha12 key per slot (temperature > 0, orc_asr_set_seed) */
+  uint64_t* rng_pos;        /* [B] words drawn so far */
   size_t model_step_idx;
   /* message queue of the last step */
   dsm_asr_msg* msgs;
@@ -1782,10 +1784,6 @@ static void push_msg(orc_asr* a, dsm_asr_msg m, const uint32_t* toks) {
 
 orc_asr* orc_asr_create(const dsm_asr_config* cfg, int batch_size, const char* lm_path, const char* mimi_path,
                         char* err, size_t errcap) {
-  if (cfg->temperature > 0.0f) {
-    snprintf(err, errcap, "temperature > 0 (gumbel_softmax, core/asr.rs:211-215) is outside the hot path");
-    return NULL;
-  }
   wsrc sl = {dsm_st_open(lm_path, err, errcap), err, errcap, 0};
   if (!sl.f) return NULL;
   wsrc sm = {dsm_st_open(mimi_path, err, errcap), err, errcap, 0};
@@ -1808,6 +1806,9 @@ orc_asr* orc_asr_create(const dsm_asr_config* cfg, int batch_size, const char* l
   }
   /* State::new — core/asr.rs:65-88 */
   a->batch = (orc_item*)xcalloc(batch_size, sizeof(orc_item));
+  a->rng_key = (uint32_t*)xcalloc((size_t)batch_size * 8, sizeof(uint32_t));
+  a->rng_pos = (uint64_t*)xcalloc(batch_size, sizeof(uint64_t));
+  for (int b = 0; b < batch_size; ++b) dsm_seed_from_u64(0x5EED0000ull + (uint64_t)b, a->rng_key + (size_t)b * 8);
   for (int b = 0; b < batch_size; ++b) a->batch[b].text_token = (uint32_t)cfg->text_in_vocab_size - 1; /* text_start_token */
   a->next_codebooks = (uint32_t*)xmalloc(sizeof(uint32_t) * (size_t)batch_size * cfg->audio_codebooks);
   for (int i = 0; i < batch_size * cfg->audio_codebooks; ++i) a->next_codebooks[i] = (uint32_t)cfg->audio_vocab_size - 1; /* audio_pad_token */
@@ -1821,7 +1822,7 @@ void orc_asr_destroy(orc_asr* a) {
   mimi_free(a->mimi[1]);
   if (a->batch)
     for (int b = 0; b < a->B; ++b) free(a->batch[b].word_tokens);
-  free(a->batch); free(a->next_codebooks); free(a->msgs); free(a->msg_tokens);
+  free(a->batch); free(a->rng_key); free(a->rng_pos); free(a->next_codebooks); free(a->msgs); free(a->msg_tokens);
   free(a);
 }
 
@@ -1877,13 +1878,22 @@ int orc_asr_step_tokens(orc_asr* a, const uint32_t* codes, const uint8_t* mask, 
     m.step_idx = (int)a->model_step_idx;
     push_msg(a, m, NULL);
   }
-  /* argmax (temperature <= 0) — :208-217 */
+  /* argmax (temperature <= 0), or candle_nn::sampling::gumbel_softmax with the slot's seeded stream (dsm_sampling.h) — :208-217 */
   const int V = a->cfg.text_out_vocab_size;
   for (int b = 0; b < B; ++b) {
     const float* lg = a->lm->dbg_logits + (size_t)b * V;
     int best = 0;
-    for (int j = 1; j < V; ++j)
-      if (lg[j] > lg[best]) best = j;
+    if (a->cfg.temperature > 0.0f) {
+      float bv = 0.0f;
+      for (int j = 0; j < V; ++j) {
+        const float v = dsm_gumbel_value(lg[j], dsm_chacha_word(a->rng_key + (size_t)b * 8, a->rng_pos[b] + (uint64_t)j, 12), a->cfg.temperature);
+        if (j == 0 || v > bv) { bv = v; best = j; }
+      }
+      if (mask[b]) a->rng_pos[b] += (uint64_t)(((V + 15) / 16) * 16);
+    } else {
+      for (int j = 1; j < V; ++j)
+        if (lg[j] > lg[best]) best = j;
+    }
     uint32_t text_token = (uint32_t)best;
     text_tokens_out[b] = text_token;
     if (!mask[b]) continue; /* :221-223 */
@@ -1995,6 +2005,13 @@ int orc_debug_read(orc_asr* a, const char* name, float* out, size_t cap) {
 }
 
 /* ---- thin exports of the shared math (tests compare them with libm) ---- */
+float orc_logf(float x) { return dsm_logf(x); }
+int orc_asr_set_seed(orc_asr* a, int slot, uint64_t seed) {
+  if (!a || slot < 0 || slot >= a->B) return -1;
+  dsm_seed_from_u64(seed, a->rng_key + (size_t)slot * 8);
+  a->rng_pos[slot] = 0;
+  return 0;
+}
 float orc_expf(float x) { return dsm_expf(x); }
 float orc_elu(float x) { return dsm_elu(x); }
 float orc_silu(float x) { return dsm_silu(x); }

@@ -34,6 +34,7 @@ int orc_mimi_decode_step(orc_asr*, int side, const uint32_t* codes, const uint8_
 int orc_asr_step_tokens(orc_asr*, const uint32_t* codes, const uint8_t* mask, uint32_t* text_tokens_out,
                         float* vad_prs_out);
 int orc_asr_reset_slot(orc_asr*, int slot);
+int orc_asr_set_seed(orc_asr*, int slot, uint64_t seed); /* temperature > 0: dsm_asr_set_seed's counterpart */
 int orc_mimi_reset_slot(orc_asr*, int side, int slot);
 int orc_asr_poll_msgs(orc_asr*, dsm_asr_msg* msgs, int cap, uint32_t* tokens_out, int tokens_cap);
 int orc_debug_read(orc_asr*, const char* name, float* out, size_t cap);
@@ -91,6 +92,7 @@ void orc_convtr1d_reset_batch_idx(orc_convtr1d*, int b);
 extern "C" {
 #endif
 float orc_expf(float x);
+float orc_logf(float x);
 float orc_elu(float x);
 float orc_silu(float x);
 float orc_gelu_erf(float x);

@@ -35,6 +35,9 @@ def lib():
         L.orc_asr_step_tokens.argtypes = [vp, vp, vp, vp, vp]
         L.orc_mimi_decode_step.argtypes = [vp, C.c_int, vp, vp, vp]
         L.orc_asr_reset_slot.argtypes = [vp, C.c_int]
+        L.orc_asr_set_seed.argtypes = [vp, C.c_int, C.c_uint64]
+        L.orc_logf.argtypes = [C.c_float]
+        L.orc_logf.restype = C.c_float
         L.orc_mimi_reset_slot.argtypes = [vp, C.c_int, C.c_int]
         L.orc_asr_poll_msgs.argtypes = [vp, C.POINTER(AsrMsg), C.c_int, vp, C.c_int]
         L.orc_debug_read.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
@@ -192,6 +195,9 @@ class OracleAsr:
 
     def reset_batch_idx(self, slot):
         self.L.orc_asr_reset_slot(self.h, slot)
+
+    def set_seed(self, slot, seed):
+        self.L.orc_asr_set_seed(self.h, slot, seed)
 
     def mimi_reset_batch_idx(self, slot, side=0):
         self.L.orc_mimi_reset_slot(self.h, side, slot)

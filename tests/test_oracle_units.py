@@ -138,3 +138,22 @@ def test_rope_is_a_rotation(orc):
     want[1::2] = x[0::2] * s + x[1::2] * c
     assert np.abs(y - want).max() <= 1e-6
     assert abs(np.linalg.norm(y) - np.linalg.norm(x)) <= 1e-5
+
+
+def test_logf_against_libm_and_gumbel_noise_is_gumbel(orc):
+    """dsm_logf (r04: the Gumbel noise of candle_nn::sampling::gumbel_softmax, core/asr.rs:211-215): < 1 ulp of libm over the
+    ranges the sampler uses — u in [1e-7, 0.999) and -ln u in (1e-3, 16.2) — and over the whole normal / subnormal range; and the
+    noise -ln(-ln u) built from ChaCha words has the Gumbel mean (Euler's constant) and variance (pi^2 / 6)."""
+    import oracle
+    L = oracle.lib()
+    rng = np.random.default_rng(3)
+    xs = np.concatenate([rng.uniform(1e-7, 0.999, 200000), rng.uniform(1e-3, 16.2, 200000), np.exp(rng.uniform(-100, 88, 100000)),
+                         [1.0, 2.0, 0.5, 1e-38, 1e-44, 3.4e38, np.float32(np.sqrt(2)), np.float32(np.sqrt(0.5))]]).astype(np.float32)
+    got = np.array([L.orc_logf(float(x)) for x in xs[:60000]], dtype=np.float32)
+    ref = np.log(xs[:60000].astype(np.float64))
+    ulp = np.spacing(np.abs(ref).astype(np.float32)).astype(np.float64)
+    assert np.max(np.abs(got.astype(np.float64) - ref) / np.maximum(ulp, 1e-45)) < 1.0
+    assert L.orc_logf(1.0) == 0.0
+    u = rng.uniform(1e-7, 0.999, 50000).astype(np.float32)
+    g = -np.array([L.orc_logf(-L.orc_logf(float(v))) for v in u[:50000]], dtype=np.float64)
+    assert abs(g.mean() - 0.5772) < 0.02 and abs(g.var() - np.pi ** 2 / 6) < 0.06

@@ -87,3 +87,35 @@ def test_tiny_batch_sizes(gpu, dsm, lib, orc, tiny_weights):
     cfg = dsm.config_tiny()
     for B in (1, 17):
         run_pair(dsm, orc, cfg, B, *tiny_weights, steps=4, mask_fn=lambda s: [1] * B)
+
+
+def test_tiny_temperature_above_zero_gumbel_sampling(gpu, dsm, lib, orc, tiny_weights):
+    """temperature > 0 (core/asr.rs:211-215, candle_nn::sampling::gumbel_softmax) with this engine's seeded per-slot noise
+    streams (dsm_asr_set_seed): engine == oracle token for token through masks, a reset and a re-seed; T = 1 (the `logits -
+    minus_g` form) and T = 0.7; the sampled tokens differ from the argmax run and between seeds.  The reference's own draw is
+    unseeded: parity vs Candle unpinned by construction."""
+    logs = {}
+    for T in (1.0, 0.7):
+        cfg = dsm.config_tiny()
+        cfg.temperature = T
+        rng = np.random.default_rng(5)
+        masks = (rng.random((24, 4)) < 0.8).astype(np.uint8)
+        masks[:, 0] = 1
+        logs[T] = run_pair(dsm, orc, cfg, 4, *tiny_weights, steps=24, mask_fn=lambda s: masks[s], resets={9: [2]})
+    greedy = run_pair(dsm, orc, dsm.config_tiny(), 4, *tiny_weights, steps=24, mask_fn=lambda s: [1, 1, 1, 1])
+    assert any(not np.array_equal(a[1], b[1]) for a, b in zip(logs[1.0], greedy))
+    # two seeds, two token streams; the same seed, the same stream
+    from dsm_amd import synth
+    cfg = dsm.config_tiny()
+    cfg.temperature = 1.0
+    pcm = synth.synth_pcm(2, 12)
+    outs = []
+    for seeds in ((11, 11), (11, 12)):
+        eng = dsm.AsrEngine(cfg, 2, *tiny_weights)
+        for slot, sd in enumerate(seeds):
+            eng.set_seed(slot, sd)
+        toks = [eng.step_pcm(np.stack([pcm[s][0], pcm[s][0]]), np.ones(2, np.uint8))[1].copy() for s in range(12)]
+        outs.append(np.stack(toks))
+        eng.close()
+    assert np.array_equal(outs[0][:, 0], outs[0][:, 1]) and np.array_equal(outs[0][:, 0], outs[1][:, 0])
+    assert not np.array_equal(outs[1][:, 0], outs[1][:, 1])
