@@ -57,8 +57,13 @@ def test_the_two_modes_differ_in_bits_not_in_value(gpu, dsm, lib, tiny_weights):
     ("bf16_hd128_ctx300", dict(lm_heads=4, lm_head_dim=128, lm_context=300, kv_bf16=1), 40),
     ("f32_hd64_ctx300", dict(lm_heads=8, lm_head_dim=64, lm_context=300, kv_bf16=0, mimi_head_dim=32, mimi_context=600), 24),
 ])
-def test_medium_two_chunk_models_bx3(gpu, dsm, lib, orc, name, kw, frames):
+@pytest.mark.parametrize("wk_norm", ["0", "1"])
+def test_medium_two_chunk_models_bx3(gpu, dsm, lib, orc, name, kw, frames, wk_norm, monkeypatch):
+    """d_model 512 = two K-chunks: split-K slabs through gemm_bx3u_kernel + the attention prologue's ordered reduce, and the
+    whole-K forms (r04): the gate through gemm_wk_kernel; with DSM_WK_NORM=1 also out_proj whole-K with the residual in its epilogue
+    and norm2 in the gate's prologue (gemm_wkn_kernel: waves 2 and 3 own no chunk and contribute +0 totals)."""
     from dsm_amd import synth
+    monkeypatch.setenv("DSM_WK_NORM", wk_norm)
     cfg = dsm.config_medium(**kw)
     cfg.dot_mode = 1
     lm, mimi = synth.make_synth_weights(cfg, WEIGHTS_DIR, tag="medium_" + name)
