@@ -1121,6 +1121,7 @@ struct AttnFused {
   const float* rope_cs;
   const uint32_t* widx;
   int nt;  // K / V rows with non-temporal loads (DSM_ATTN_NT)
+  int q_only;  // the slabs hold a [M][d] query projection only (cross-attention, r04): no K / V rows, no RoPE, nothing scattered
 };
 
 template <typename KVT, int HD, int T>
@@ -1158,7 +1159,7 @@ __global__ __launch_bounds__(256, 4) void attn_kernel(float* __restrict__ out, c
   const KVT* Vb = vcache + ((long)b * H + h) * ctx * HD;
   if (T == 1 && fq.ws) {
     // row m = b of the [M][3d] QKV product: q at n = h*HD + i, k at d + ..., v at 2d + ... (core/batched_transformer.rs:77-82)
-    if (tid < 3 * HD / 4) {
+    if (tid < (fq.q_only ? HD / 4 : 3 * HD / 4)) {
       const int part = tid / (HD / 4), i0 = 4 * (tid % (HD / 4));
       const f32x4 v = slab_sum(fq.ws + (long)b * fq.ld + part * d + h * HD + i0, fq.cstride, fq.chunks);
       float o[4] = {v[0], v[1], v[2], v[3]};
@@ -1634,28 +1635,39 @@ __global__ void dep_gather_kernel(float* __restrict__ e, const float* __restrict
 //   ring bookkeeping of ScatteredCacheBuilder for one new position (kv_builder_kernel's thread 0)
 //   xn = norm1 of layer 0 over x, canonical row reduction (row_norm_kernel's arithmetic)
 // `rv + o` of the GEMM epilogue is a single f32 add either way: same bits as the five launches.
-__global__ __launch_bounds__(256) void dep_head_kernel(float* __restrict__ x, float* __restrict__ xn,
-                                                       const float* __restrict__ table, const uint32_t* __restrict__ last_tok,
-                                                       int vocab, int D, int rps, const float* __restrict__ proj, long proj_ld,
-                                                       uint32_t* __restrict__ pos, uint32_t* __restrict__ idx,
-                                                       const uint8_t* __restrict__ active, uint32_t* __restrict__ start_pos,
-                                                       uint32_t* __restrict__ widx, int ctx, const float* __restrict__ nw,
-                                                       const float* __restrict__ nb, float eps, int rms) {
-  __shared__ float red[8];
-  const int b = blockIdx.x;
+struct DepHeadArgs {
+  float* x;             // [rows][D] the slice's input (null: no head — dep_argmax_kernel's last slice)
+  float* xn;            // [rows][D] norm1 of layer 0 over x
+  const float* table;   // emb_k, [vocab][D]
+  int vocab, D, rps;
+  const float* proj;    // this slice's weight group inside the stacked projections, row stride proj_ld
+  long proj_ld;
+  uint32_t* pos;
+  uint32_t* idx;
+  const uint8_t* active;  // per batch row
+  uint32_t* start_pos;
+  uint32_t* widx;
+  int ctx;
+  const float* nw;
+  const float* nb;
+  float eps;
+  int rms;
+};
+// one batch row b with the slot's token t; all 256 threads; `red` = 8 floats of LDS (a barrier separates two calls)
+__device__ __forceinline__ void dep_head_row(const DepHeadArgs& h, int b, uint32_t t, float* red) {
   if (threadIdx.x == 0) {  // kv_builder_kernel, T = 1
-    const uint32_t p = pos[b], i = idx[b];
-    start_pos[b] = p;
-    widx[b] = i;  // active: (i + 0) % ctx = i (i < ctx); inactive: i
-    if (active[b]) {
-      pos[b] = p + 1;
-      idx[b] = (uint32_t)((i + 1) % ctx);
+    const uint32_t p = h.pos[b], i = h.idx[b];
+    h.start_pos[b] = p;
+    h.widx[b] = i;  // active: (i + 0) % ctx = i (i < ctx); inactive: i
+    if (h.active[b]) {
+      h.pos[b] = p + 1;
+      h.idx[b] = (uint32_t)((i + 1) % h.ctx);
     }
   }
-  uint32_t t = last_tok[b / rps];
-  if (t >= (uint32_t)vocab) t = 0;
-  const float* er = table + (long)t * D;
-  const float* pr = proj + (long)b * proj_ld;
+  if (t >= (uint32_t)h.vocab) t = 0;
+  const int D = h.D;
+  const float* er = h.table + (long)t * D;
+  const float* pr = h.proj + (long)b * h.proj_ld;
   float4 v[DSM_ROW_ITS];
   float s = 0.0f, s2 = 0.0f;
 #pragma unroll
@@ -1666,7 +1678,7 @@ __global__ __launch_bounds__(256) void dep_head_kernel(float* __restrict__ x, fl
       const float4 ev = *reinterpret_cast<const float4*>(er + i);
       const float4 pv = *reinterpret_cast<const float4*>(pr + i);
       v[it] = make_float4(ev.x + pv.x, ev.y + pv.y, ev.z + pv.z, ev.w + pv.w);
-      *reinterpret_cast<float4*>(x + (long)b * D + i) = v[it];
+      *reinterpret_cast<float4*>(h.x + (long)b * D + i) = v[it];
       s = s + v[it].x; s2 = DSM_FMAF(v[it].x, v[it].x, s2);
       s = s + v[it].y; s2 = DSM_FMAF(v[it].y, v[it].y, s2);
       s = s + v[it].z; s2 = DSM_FMAF(v[it].z, v[it].z, s2);
@@ -1674,7 +1686,12 @@ __global__ __launch_bounds__(256) void dep_head_kernel(float* __restrict__ x, fl
     }
   }
   block_row_sums(s, s2, red);
-  row_norm_apply(v, s, s2, D, eps, rms, nw, nb, xn + (long)b * D);
+  row_norm_apply(v, s, s2, D, h.eps, h.rms, h.nw, h.nb, h.xn + (long)b * D);
+}
+__global__ __launch_bounds__(256) void dep_head_kernel(DepHeadArgs h, const uint32_t* __restrict__ last_tok) {
+  __shared__ float red[8];
+  const int b = blockIdx.x;
+  dep_head_row(h, b, last_tok[b / h.rps], red);
 }
 
 // Classifier-free guidance mix of a slot's two batch rows — core/tts_streaming.rs:166-172, core/lm.rs:718-721:
@@ -1727,12 +1744,21 @@ __device__ __forceinline__ f32x4 logit4(const LogitSrc& s, int row, int V, int j
   return *reinterpret_cast<const f32x4*>(s.rows + (long)row * V + j);
 }
 
-__global__ void dep_argmax_kernel(LogitSrc src, int V, int k, int S, uint32_t* __restrict__ lat,
-                                  uint32_t* __restrict__ last_tok, const uint8_t* __restrict__ run,
-                                  const uint8_t* __restrict__ forced, uint32_t pad, SampleArgs sa, int lds_row_off) {
+// r04: the sampler's workgroup also runs the NEXT slice's head for its slot's batch rows (dep_head_row: embedding of the token it
+// just chose + that slice's projection, ring bookkeeping, norm1) — one launch less per slice; slots that are not running keep
+// their last token, as the separate head launch found it.
+__global__ __launch_bounds__(256) void dep_argmax_kernel(LogitSrc src, int V, int k, int S, uint32_t* __restrict__ lat,
+                                                          uint32_t* __restrict__ last_tok, const uint8_t* __restrict__ run,
+                                                          const uint8_t* __restrict__ forced, uint32_t pad, SampleArgs sa, int lds_row_off,
+                                                          DepHeadArgs next) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ uint32_t s_next;
+  __shared__ float hred[8];
   const int b = blockIdx.x;
-  if (!run[b]) return;
+  if (!run[b]) {
+    if (!next.x) return;
+    if (threadIdx.x == 0) s_next = last_tok[b];
+  } else {
   float* logits = reinterpret_cast<float*>(smem + lds_row_off);  // the slot's row, staged once (V % 4 == 0)
   const bool mix = src.rps == 2 && src.cfg_on[b];
   if (src.ws || (V & 3) == 0) {
@@ -1770,7 +1796,17 @@ __global__ void dep_argmax_kernel(LogitSrc src, int V, int k, int S, uint32_t* _
     tok = (uint32_t)block_argmax_first(logits, V);
   if (threadIdx.x == 0) {
     lat[(long)b * S + k] = tok;
-    last_tok[b] = (forced[b] && k > 0) ? pad : tok;
+    const uint32_t nt = (forced[b] && k > 0) ? pad : tok;
+    last_tok[b] = nt;
+    s_next = nt;
+  }
+  if (!next.x) return;
+  }
+  __syncthreads();
+  const uint32_t t = s_next;
+  for (int j = 0; j < next.rps; ++j) {
+    if (j > 0) __syncthreads();  // hred is reused
+    dep_head_row(next, b * next.rps + j, t, hred);
   }
 }
 
