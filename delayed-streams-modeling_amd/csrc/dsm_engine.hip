@@ -232,6 +232,7 @@ struct dsm_engine {
   bool wk_norm = false;       // DSM_WK_NORM=1: where the MLP input GEMM runs whole-K, norm2 moves into its prologue (gemm_wkn_kernel) and out_proj
                               // stores the residual stream itself (two launches fewer per layer; measured 6.56 against 6.45 ms per TTS step: off)
   int wk_gate_max_chunks = 4; // DSM_WK_GATE_CHUNKS: gated-MLP input GEMMs with at most this many K-chunks run whole-K-in-the-workgroup
+  bool bx3u_m64 = true;  // DSM_BX3U_M64=0: 33..64-row narrow GEMMs stay on one 64-row tile
                               // (gemm_wk_kernel: no slabs, no reduce launch); 0: never
   int prio_hi = 0;
   bool serialize_groups = false;  // dsm_debug_serialize_groups: every group on the model stream (profiling aid)
@@ -991,6 +992,12 @@ int launch_gemm_tiled(dsm_engine* e, hipStream_t st, GemmArgs& a) {
   }
   int MT = a.M > 32 ? 4 : (a.M > 16 ? 2 : 1);
   while (MT > 1 && (long)gx * chunks * ((a.M + 16 * MT - 1) / (16 * MT)) < 256) MT /= 2;  // cover the 256 CUs
+  // 33..64 rows, dot_mode 1, a launch of at most 256 workgroups (out_proj of a 2048-wide model): two 32-row z-tiles on
+  // gemm_bx3u_kernel instead of one 64-row tile on gemm_bx3_kernel — 12.8 against 15.4 us with its reduce (experiments/gemm_wk_probe 3,
+  // form 5); the wider launches (QKV, gate, ff_out) tie or lose that way and keep MT = 4.  DSM_BX3U_M64=0: off.
+  if (MT == 4 && e->bx3u && e->bx3u_m64 && e->dot_mode == 1 && sizeof(WT) == 2 && chunks > 1 && a.chunk_loop == 0 && a.M <= 64 &&
+      (long)gx * chunks <= 256 && EPI == EPI_STORE)
+    MT = 2;
   // one K-chunk and thousands of m-tiles (the first SEANet layers at large batches: K = 32..192, M = B x 1920): a
   // workgroup is one short dependent chain — loads, one to six MFMA blocks, residual load, store — so what counts is how
   // many of them a CU holds; gemm_tile_kernel's up-front window of eight blocks costs 200-230 VGPRs (two workgroups per CU),

@@ -82,9 +82,10 @@ def test_stt_1b_real_dimensions_bx3(gpu, dsm, lib, orc):
     run_pair(dsm, orc, cfg, 3, lm, mimi, steps=3, mask_fn=lambda s: [1, 1, s != 1])
 
 
-@pytest.mark.parametrize("B", [64, 1024])
+@pytest.mark.parametrize("B", [64, 128, 1024])
 def test_real_dimensions_large_batches_by_slot_independence_bx3(gpu, dsm, lib, B):
-    """B = 64: two stream groups of 32 (MT = 2, split-K slabs, fused QKV prologue); B = 1024: gemm_bx3_kernel's whole-K loop
+    """B = 64: two stream groups of 32 (MT = 2, split-K slabs, fused QKV prologue); B = 128: groups of 64 rows — one 64-row tile on
+    gemm_bx3_kernel for QKV / gate / ff_out, two 32-row z-tiles on gemm_bx3u_kernel for out_proj (DSM_BX3U_M64); B = 1024: gemm_bx3_kernel's whole-K loop
     form over 8 m-tiles per group.  Streams never interact: every slot must equal, bit for bit, the same stream stepped by the
     B = 4 engine that test_stt_1b_real_dimensions_bx3 ties to the oracle."""
     from dsm_amd import synth
