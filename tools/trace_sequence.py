@@ -2,7 +2,9 @@
 """Launch sequence of ONE step from a rocprofv3 kernel-trace CSV: every kernel between two launches of the marker kernel,
 in start order, with its duration and the gap to the previous kernel's end.  usage: trace_sequence.py DIR MARKER [step]"""
 import csv, glob, os, sys
-f = max(glob.glob(sys.argv[1] + "/*/*_kernel_trace.csv"), key=os.path.getsize)
+files = glob.glob(sys.argv[1] + "/*/*_kernel_trace.csv")
+newest = max(os.path.getmtime(x) for x in files)  # the newest visit's bench process (gpurun_out/ keeps earlier visits' files)
+f = max((x for x in files if newest - os.path.getmtime(x) < 600), key=os.path.getsize)
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 marker = sys.argv[2]
 idx = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]

@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Per-(kernel, grid) summary of a rocprofv3 kernel-trace CSV; also prints the inter-kernel idle time."""
 import collections, csv, glob, os, sys
-f = max(glob.glob(sys.argv[1] + "/*/*_kernel_trace.csv"), key=os.path.getsize)  # the bench process (child processes it spawns are traced too)
+# gpurun_out/ accumulates across visits to the GPU box (results are merged back, never deleted): take the NEWEST visit's files
+# (written within ten minutes of the newest one) and, among those, the bench process (the largest: child processes are traced too)
+files = glob.glob(sys.argv[1] + "/*/*_kernel_trace.csv")
+newest = max(os.path.getmtime(x) for x in files)
+f = max((x for x in files if newest - os.path.getmtime(x) < 600), key=os.path.getsize)
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 agg = collections.defaultdict(list)
 for r in rows:

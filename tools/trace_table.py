@@ -3,7 +3,10 @@ import csv, glob, sys, collections
 d = sys.argv[1]
 sub = sys.argv[2] if len(sys.argv) > 2 else ""
 rows = collections.OrderedDict()
-for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
+import os
+files = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)
+newest = max(os.path.getmtime(x) for x in files)  # gpurun_out/ keeps earlier visits' files: only the newest visit's (ten minutes)
+for f in (x for x in files if newest - os.path.getmtime(x) < 600):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
         if sub and sub not in n:
