@@ -233,6 +233,7 @@ struct dsm_engine {
                               // stores the residual stream itself (two launches fewer per layer; measured 6.56 against 6.45 ms per TTS step: off)
   int wk_gate_max_chunks = 4; // DSM_WK_GATE_CHUNKS: gated-MLP input GEMMs with at most this many K-chunks run whole-K-in-the-workgroup
   bool bx3u_m64 = true;  // DSM_BX3U_M64=0: 33..64-row narrow GEMMs stay on one 64-row tile
+  bool attn_small = true;  // DSM_ATTN_SMALL=0: rings of at most 32 positions use attn_kernel too
                               // (gemm_wk_kernel: no slabs, no reduce launch); 0: never
   int prio_hi = 0;
   bool serialize_groups = false;  // dsm_debug_serialize_groups: every group on the model stream (profiling aid)

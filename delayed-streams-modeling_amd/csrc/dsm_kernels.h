@@ -1326,6 +1326,130 @@ __global__ __launch_bounds__(256, 4) void attn_kernel(float* __restrict__ out, c
   if (ts_last) atomicMax(&ts[1], wall_clock64());
 }
 
+// ---- attention over a SHORT ring (r04): T = 1, at most 32 positions, head_dim 64 — the DepFormer's rings (one position per
+// codebook slice) and their cousins in small test models.  attn_kernel spends a 256-thread workgroup, five barriers and a
+// 128-key software pipeline on what is at most 32 keys; here one WAVE owns a (slot, head) and a workgroup four of them.
+// Same arithmetic, same canonical order: key j belongs to canonical wave j / 8 and lane group j % 8, so the physical wave walks
+// the four canonical waves' keys (one key per lane group each), keeps the four partial outputs apart, folds each over its lane
+// groups with the same butterfly (offsets 32, 16, 8) and adds them left to right; the softmax sum sits one probability per lane
+// (thread j of canonical wave 0 in attn_kernel) under the same 64-lane butterfly, the other canonical waves contribute +0.
+// Keys beyond the valid range contribute fma(0, v, +0) = +0 there and nothing here.
+template <typename KVT, int HD>
+__global__ __launch_bounds__(256) void attn_small_kernel(float* __restrict__ out, const float* __restrict__ qbuf,
+                                                         const KVT* __restrict__ kcache, const KVT* __restrict__ vcache,
+                                                         const uint32_t* __restrict__ start_pos, const uint8_t* __restrict__ active,
+                                                         int BH, int H, int ctx, int d, AttnFused fq) {
+  static_assert(HD == 64, "one lane group of 8 lanes per key");
+  constexpr int LPK = HD / 8;
+  __shared__ __attribute__((aligned(16))) float lds_all[4][32 + HD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int unit = blockIdx.x * 4 + wave;
+  const int uc = unit < BH ? unit : BH - 1;
+  const int b = uc / H, h = uc % H;
+  const bool on = unit < BH && active[b];
+  float* sc = lds_all[wave];  // [32] scores, then probabilities
+  float* qs = sc + 32;        // [HD] the query (fused prologue)
+  const int g = lane / LPK, li = lane % LPK;
+  const uint32_t sp = start_pos[b];
+  const long e1 = (long)sp;
+  const int nvalid = (int)((e1 + 1 < (long)ctx) ? e1 + 1 : ctx);
+  const float scale = (float)(1.0 / sqrt((double)HD));
+  const KVT* Kb = kcache + ((long)b * H + h) * ctx * HD;
+  const KVT* Vb = vcache + ((long)b * H + h) * ctx * HD;
+  if (fq.ws) {  // attn_kernel's prologue, lane for thread
+    if (on && lane < (fq.q_only ? HD / 4 : 3 * HD / 4)) {
+      const int part = lane / (HD / 4), i0 = 4 * (lane % (HD / 4));
+      const f32x4 v = slab_sum(fq.ws + (long)b * fq.ld + part * d + h * HD + i0, fq.cstride, fq.chunks);
+      float o[4] = {v[0], v[1], v[2], v[3]};
+      if (part < 2 && fq.rope_cs) {
+        const float4 cs = *reinterpret_cast<const float4*>(fq.rope_cs + ((long)b * (HD / 2) + (i0 >> 1)) * 2);
+        const float co[2] = {cs.x, cs.z}, si[2] = {cs.y, cs.w};
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          float x0 = v[2 * p], x1 = v[2 * p + 1];
+          float t0 = x0 * co[p], t1 = x1 * si[p], t2 = x0 * si[p], t3 = x1 * co[p];
+          o[2 * p] = t0 - t1;
+          o[2 * p + 1] = t2 + t3;
+        }
+      }
+      if (part == 0) {
+        qs[i0] = o[0]; qs[i0 + 1] = o[1]; qs[i0 + 2] = o[2]; qs[i0 + 3] = o[3];
+      } else {
+        KVT* row = const_cast<KVT*>(part == 1 ? Kb : Vb) + (long)fq.widx[b] * HD + i0;
+        store_kv4(row, o);
+      }
+    }
+    __syncthreads();  // the new K / V row is visible to this workgroup's loads (every wave arrives: no wave has left yet)
+  }
+  if (!on) return;
+  float qv[8];
+  if (fq.ws) {
+#pragma unroll
+    for (int dd = 0; dd < 8; ++dd) qv[dd] = qs[8 * li + dd];
+  } else {
+    const float* qp = qbuf + (long)b * d + h * HD + 8 * li;
+    const float4 q0 = *reinterpret_cast<const float4*>(qp), q1 = *reinterpret_cast<const float4*>(qp + 4);
+    qv[0] = q0.x; qv[1] = q0.y; qv[2] = q0.z; qv[3] = q0.w; qv[4] = q1.x; qv[5] = q1.y; qv[6] = q1.z; qv[7] = q1.w;
+  }
+  const int jlast = nvalid - 1;
+  Raw8<KVT> rk[4], rv[4];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const int jj = min(8 * w + g, jlast);  // clamped: loaded, never used
+    rk[w].load(Kb + (long)jj * HD + 8 * li);
+  }
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const int jj = min(8 * w + g, jlast);
+    rv[w].load(Vb + (long)jj * HD + 8 * li);
+  }
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const int j = 8 * w + g;
+    float kv[8];
+    rk[w].unpack(kv);
+    float p = 0.0f;
+#pragma unroll
+    for (int dd = 0; dd < 8; ++dd) p = DSM_FMAF(qv[dd], kv[dd], p);
+#pragma unroll
+    for (int off = LPK / 2; off >= 1; off >>= 1) p = p + __shfl_xor(p, off, 64);
+    if (li == 0 && j < nvalid) sc[j] = p * scale;  // T = 1: every written slot is visible
+  }
+  // softmax_last_dim: thread j of canonical wave 0 owns probability j
+  float m = -DSM_INF_F;
+  if (lane < nvalid) m = fmaxf(m, sc[lane]);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  float tp = 0.0f;
+  if (lane < nvalid) {
+    const float p = dsm_expf(sc[lane] - m);
+    sc[lane] = p;
+    tp = tp + p;
+  }
+  tp = wave_sum64(tp);
+  const float lsum = ((tp + 0.0f) + 0.0f) + 0.0f;  // canonical waves 1..3 hold no probability
+  float tot[8];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const int j = 8 * w + g;
+    float vv[8];
+    rv[w].unpack(vv);
+    const float wgt = (j < nvalid) ? sc[j] / lsum : 0.0f;
+#pragma unroll
+    for (int dd = 0; dd < 8; ++dd) {
+      float v = (j < nvalid) ? DSM_FMAF(wgt, vv[dd], 0.0f) : 0.0f;
+#pragma unroll
+      for (int off = 32; off >= LPK; off >>= 1) v = v + __shfl_xor(v, off, 64);
+      tot[dd] = w == 0 ? v : tot[dd] + v;  // ((r0 + r1) + r2) + r3
+    }
+  }
+  if (g == 0) {
+    float* o = out + (long)b * d + h * HD + 8 * li;
+    *reinterpret_cast<float4*>(o) = make_float4(tot[0], tot[1], tot[2], tot[3]);
+    *reinterpret_cast<float4*>(o + 4) = make_float4(tot[4], tot[5], tot[6], tot[7]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // ScatteredCacheBuilder step on the device (core/kv_cache.rs:119-237): write slots, start
 // positions, advance for active slots, and the RoPE table for the positions AFTER the advance
