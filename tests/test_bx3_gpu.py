@@ -56,6 +56,10 @@ def test_the_two_modes_differ_in_bits_not_in_value(gpu, dsm, lib, tiny_weights):
 @pytest.mark.parametrize("name,kw,frames", [
     ("bf16_hd128_ctx300", dict(lm_heads=4, lm_head_dim=128, lm_context=300, kv_bf16=1), 40),
     ("f32_hd64_ctx300", dict(lm_heads=8, lm_head_dim=64, lm_context=300, kv_bf16=0, mimi_head_dim=32, mimi_context=600), 24),
+    # rings of at most 32 positions with head_dim 64: attn_small_kernel (one wave per (slot, head)) with the fused QKV prologue,
+    # RoPE and ring wrap after 24 frames, on the bf16 and on the f32 ring
+    ("bf16_hd64_ctx24", dict(lm_heads=8, lm_head_dim=64, lm_context=24, kv_bf16=1), 40),
+    ("f32_hd64_ctx32", dict(lm_heads=8, lm_head_dim=64, lm_context=32, kv_bf16=0), 40),
 ])
 @pytest.mark.parametrize("wk_norm", ["0", "1"])
 def test_medium_two_chunk_models_bx3(gpu, dsm, lib, orc, name, kw, frames, wk_norm, monkeypatch):

@@ -14,10 +14,12 @@ pytestmark = pytest.mark.gpu
 WDIR = os.environ.get("DSM_WEIGHTS_DIR", "/tmp/dsm_weights")
 
 
-def _cfg(dsm, **kw):
+def _cfg(dsm, hd64=False, **kw):
     from dsm_amd import synth
     cfg = dsm.config_tts_tiny(cross_attention=True, **kw)
-    tag = "tts_tiny_ca" + ("_kvd%d" % cfg.ca_dim if cfg.ca_dim else "") + ("_rms" if cfg.ca_norm else "")
+    if hd64:  # head_dim 64 with rings / sources of at most 32 rows: attn_small_kernel (self-attention from stored q, cross-attention)
+        cfg.lm.num_heads, cfg.depformer.num_heads = 2, 1
+    tag = "tts_tiny_ca" + ("_kvd%d" % cfg.ca_dim if cfg.ca_dim else "") + ("_rms" if cfg.ca_norm else "") + ("_hd64" if hd64 else "")
     return cfg, synth.make_synth_tts_weights(cfg, WDIR, tag=tag)
 
 
@@ -52,7 +54,7 @@ def _drive(dsm, orc, cfg, path, B, steps, setup, events=None, sampling=None):
 
 
 @pytest.mark.parametrize("kv_bf16", [1, 0])
-@pytest.mark.parametrize("kw", [dict(), dict(ca_dim=40), dict(ca_norm=1)])
+@pytest.mark.parametrize("kw", [dict(), dict(ca_dim=40), dict(ca_norm=1), dict(hd64=True)])
 def test_cross_attention_tiny(gpu, dsm, lib, orc, kw, kv_bf16):
     from dsm_amd import synth
     cfg, path = _cfg(dsm, **kw)
