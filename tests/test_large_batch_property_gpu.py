@@ -86,21 +86,25 @@ def test_large_batch_slots_with_equal_audio_agree_and_match_b4(gpu, dsm, lib, mo
     small.close()
 
 
-def test_tts_b384_slots_with_equal_inputs_agree_and_match_b3(gpu, dsm, lib):
-    """The same property for the TTS step (BASELINE.json configs[4] shapes; B = 32 is the oracle-compared size): at B = 384 the
+@pytest.mark.parametrize("B,dot_mode", [(384, 0), (48, 1)])
+def test_tts_b384_slots_with_equal_inputs_agree_and_match_b3(gpu, dsm, lib, B, dot_mode):
+    """(B = 48, dot_mode 1: 33..64 rows — the DepFormer gate as gemm_wk_kernel over three row tiles, narrow GEMMs as two 32-row
+    z-tiles on gemm_bx3u_kernel (the second one ragged), the others on one ragged 64-row tile; the B = 3 engine it is compared with is tied to the
+    oracle in both modes by test_tts_ca_gpu.py.)
+    The same property for the TTS step (BASELINE.json configs[4] shapes; B = 32 is the oracle-compared size): at B = 384 the
     main LM runs its 64-row whole-K loop kernels and 6144-workgroup attention launches, the depformer 32 slices of M = 384
     GEMMs with a 384-row argmax / top-k.  Slots fed the same text stream, allowed-token rule, mask and sampling seed must
     generate the same text and audio tokens and the same LM hidden state as a B = 3 engine — argmax slots and seeded
     top-k slots alike, through a paused step."""
     from dsm_amd import synth
     cfg = dsm.config_tts_v202501()
-    cfg.dot_mode = 0  # the preset says 1; this file runs mode 0 (mode 1 at these shapes: test_bx3_gpu.py)
+    cfg.dot_mode = dot_mode
     cfg.text_audio_delay_in_tokens, cfg.max_steps = 0, 32  # depformer live from the first step
     path = synth.make_synth_tts_weights(cfg, WEIGHTS_DIR, tag="tts-v202501-prop")
-    B, NS, steps = 384, 3, 5
+    NS, steps = 3, 5
     rng = np.random.default_rng(13)
     owner = rng.integers(0, NS, B)
-    owner[[0, 1, 2, 191, 192, 193, 381, 382, 383]] = [0, 1, 2, 0, 1, 2, 0, 1, 2]
+    owner[[0, 1, 2, B // 2 - 1, B // 2, B // 2 + 1, B - 3, B - 2, B - 1]] = [0, 1, 2, 0, 1, 2, 0, 1, 2]
     prev_src = rng.integers(0, cfg.text_in_vocab_size, (steps, NS)).astype(np.uint32)
     allowed_src = np.stack([np.array([int(rng.integers(4, 8000)), dsm.TTS_ALLOW_PAD_OR_EPAD, int(rng.integers(4, 8000))], dtype=np.int32)
                             for _ in range(steps)])
