@@ -43,11 +43,18 @@ __global__ __launch_bounds__(256, 2) void stream_kernel(const u32x4* __restrict_
 // for its four waves' n-tiles 4 bx + w (and, NT = 2, the tile `up` tiles further on), the eight 1 KB fragments of chunk by.
 // ORDER 0: bx = id % gx (the kernels' launch order: concurrently running workgroups are 4 n-tiles = 4 x (K / 32) KB apart);
 // ORDER 1: by = id % chunks (eight consecutive workgroups cover 4 x 64 KB contiguous pieces).
-template <int NT, int ORDER>
-__global__ __launch_bounds__(256, 2) void gemm_pattern_kernel(const u32x4* __restrict__ w, u32x4* __restrict__ out, int gx, int chunks, int kblocks, int up) {
+// XL: 16-byte activation loads per thread issued BEFORE the weights — the chunk's [32 rows][256] f32 block (32 KB, piece p = tid +
+// 256 i as in gemm_bx3u_kernel), from a 256 KB buffer every workgroup shares (L2 hits after the first touch); LDSB: bytes of static
+// LDS per workgroup (the kernels hold 48 KB: three workgroups per CU)
+template <int NT, int ORDER, int XL, int LDSB>
+__global__ __launch_bounds__(256, 2) void gemm_pattern_kernel(const u32x4* __restrict__ w, u32x4* __restrict__ out, int gx, int chunks, int kblocks, int up, const u32x4* __restrict__ xbuf) {
   const int id = blockIdx.x;
   const int bx = ORDER == 0 ? id % gx : id / chunks, by = ORDER == 0 ? id / gx : id % chunks;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ u32x4 pad[LDSB / 16 + 1];
+  u32x4 xv[XL + 1];
+#pragma unroll
+  for (int i = 0; i < XL; ++i) xv[i] = xbuf[((size_t)by * 2048 + threadIdx.x + 256 * i) & 16383];
   u32x4 v[8][NT];
 #pragma unroll
   for (int g = 0; g < 8; ++g)
@@ -55,22 +62,25 @@ __global__ __launch_bounds__(256, 2) void gemm_pattern_kernel(const u32x4* __res
     for (int nt = 0; nt < NT; ++nt) v[g][nt] = w[((size_t)(4 * bx + wave + nt * up) * kblocks + by * 8 + g) * 64 + lane];
   u32x4 acc = {0u, 0u, 0u, 0u};
 #pragma unroll
+  for (int i = 0; i < XL; ++i) acc ^= xv[i];
+  if (LDSB) { pad[threadIdx.x & (LDSB / 16 - 1)] = acc; __syncthreads(); acc ^= pad[(threadIdx.x * 7) & (LDSB / 16 - 1)]; }
+#pragma unroll
   for (int g = 0; g < 8; ++g)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc ^= v[g][nt];
   if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x9E3779B9u) out[(blockIdx.x * 256 + threadIdx.x) & 65535] = acc;
 }
-template <int NT, int ORDER>
+template <int NT, int ORDER, int XL = 0, int LDSB = 0>
 static void run_pattern(const char* name, int gx, int chunks, int up, const u32x4* w, size_t total_elems, u32x4* out) {
   const int kblocks = chunks * 8, ntiles = NT == 2 ? 2 * up : 4 * gx;
   const size_t copy = (size_t)ntiles * kblocks * 64;
   const int rot = (int)(total_elems / copy);
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int i = 0; i < rot; ++i) hipLaunchKernelGGL((gemm_pattern_kernel<NT, ORDER>), dim3(gx * chunks), dim3(256), 0, 0, w + (size_t)i * copy, out, gx, chunks, kblocks, up);
+  for (int i = 0; i < rot; ++i) hipLaunchKernelGGL((gemm_pattern_kernel<NT, ORDER, XL, LDSB>), dim3(gx * chunks), dim3(256), 0, 0, w + (size_t)i * copy, out, gx, chunks, kblocks, up, w + total_elems - 16384);
   CK(hipDeviceSynchronize());
   const int reps = 4 * rot;
   CK(hipEventRecord(e0, 0));
-  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((gemm_pattern_kernel<NT, ORDER>), dim3(gx * chunks), dim3(256), 0, 0, w + (size_t)(i % rot) * copy, out, gx, chunks, kblocks, up);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((gemm_pattern_kernel<NT, ORDER, XL, LDSB>), dim3(gx * chunks), dim3(256), 0, 0, w + (size_t)(i % rot) * copy, out, gx, chunks, kblocks, up, w + total_elems - 16384);
   CK(hipEventRecord(e1, 0));
   CK(hipDeviceSynchronize());
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -132,7 +142,11 @@ int main(int argc, char** argv) {
   printf("the GEMMs' own address pattern (fragment-major weights, registers):\n");
   run_pattern<2, 0>("gate 88 x 8, bx fastest (launch order today)", 88, 8, 352, w, elems, out);
   run_pattern<2, 1>("gate 88 x 8, chunk index fastest", 88, 8, 352, w, elems, out);
+  run_pattern<2, 0, 8, 0>("gate, bx fastest + 8 activation loads", 88, 8, 352, w, elems, out);
+  run_pattern<2, 0, 0, 49152>("gate, bx fastest + 48 KB LDS", 88, 8, 352, w, elems, out);
+  run_pattern<2, 0, 8, 49152>("gate, bx fastest + activations + 48 KB LDS", 88, 8, 352, w, elems, out);
   run_pattern<1, 0>("QKV 96 x 8, bx fastest", 96, 8, 0, w, elems, out);
+  run_pattern<1, 0, 8, 49152>("QKV, bx fastest + activations + 48 KB LDS", 96, 8, 0, w, elems, out);
   run_pattern<1, 1>("QKV 96 x 8, chunk index fastest", 96, 8, 0, w, elems, out);
   run_pattern<1, 0>("ff_out 32 x 22, bx fastest", 32, 22, 0, w, elems, out);
   run_pattern<1, 1>("ff_out 32 x 22, chunk index fastest", 32, 22, 0, w, elems, out);
