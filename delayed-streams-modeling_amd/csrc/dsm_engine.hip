@@ -233,6 +233,7 @@ struct dsm_engine {
                               // stores the residual stream itself (two launches fewer per layer; measured 6.56 against 6.45 ms per TTS step: off)
   int wk_gate_max_chunks = 4; // DSM_WK_GATE_CHUNKS: gated-MLP input GEMMs with at most this many K-chunks run whole-K-in-the-workgroup
   bool bx3u_m64 = true;  // DSM_BX3U_M64=0: 33..64-row narrow GEMMs stay on one 64-row tile
+  bool bx3u_late = true;  // DSM_BX3U_LATE=0: the 32-row gemm_bx3u_kernel requests all eight weight blocks up front (129-140 VGPRs)
   bool attn_small = true;  // DSM_ATTN_SMALL=0: rings of at most 32 positions use attn_kernel too
                               // (gemm_wk_kernel: no slabs, no reduce launch); 0: never
   int prio_hi = 0;
@@ -1060,7 +1061,8 @@ int launch_gemm_tiled(dsm_engine* e, hipStream_t st, GemmArgs& a) {
   // r04: the split-K form at M <= 32 issues every load of its chunk up front (gemm_bx3u_kernel, 48 KB of LDS at MT = 2)
 #define DSM_LAUNCH_BX3(MTv)                                                                                     \
   if (a.chunk_loop > 1) hipLaunchKernelGGL((gemm_bx3_kernel<KVT, MTv, NT, EPI, true>), grid, dim3(256), pad, st, a); \
-  else if (MTv <= 2 && e->bx3u && pad == 0) hipLaunchKernelGGL((gemm_bx3u_kernel<KVT, (MTv <= 2 ? MTv : 2), NT, EPI, 8>), grid, dim3(256), 0, st, a); \
+  else if (MTv == 2 && e->bx3u && e->bx3u_late && pad == 0) hipLaunchKernelGGL((gemm_bx3u_kernel<KVT, 2, NT, EPI, 8, 0, 4>), grid, dim3(256), 8 * 3 * 32 * 32 * 2, st, a); \
+  else if (MTv <= 2 && e->bx3u && pad == 0) hipLaunchKernelGGL((gemm_bx3u_kernel<KVT, (MTv <= 2 ? MTv : 2), NT, EPI, 8>), grid, dim3(256), 8 * 3 * 16 * (MTv <= 2 ? MTv : 2) * 32 * 2, st, a); \
   else hipLaunchKernelGGL((gemm_bx3_kernel<KVT, MTv, NT, EPI, false>), grid, dim3(256), pad, st, a);
   if (nt2) {
     hipLaunchKernelGGL((gemm_bx3_kernel<KVT, 4, (NT == 1 ? 2 : NT), (EPI == EPI_GATE ? EPI_STORE : EPI), true>), grid, dim3(256), pad, st, a);

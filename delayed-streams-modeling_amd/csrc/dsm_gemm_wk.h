@@ -202,9 +202,13 @@ __global__ __launch_bounds__(64 * NW, OCC) void gemm_wk_kernel(GemmArgs a) {
 // WL: weight layout.  0: row-major [N][Kpad]; 1: tile-major [N / 16][Kpad / 32][64 lanes][8] — the 16 x 32 fragment one wave
 // loads per block is 1 KB contiguous, a wave's chunk 8 KB; 2: chunk-major [chunk][N / 16][blocks of the chunk][64][8] — the 64
 // rows x 256 k a workgroup streams are 32 KB contiguous and consecutive workgroups follow each other in memory.
-template <typename KVT, int MT, int NT, int EPI, int HB, int WL = 0>
-__global__ __launch_bounds__(256, 2) void gemm_bx3u_kernel(GemmArgs a) {
-  __shared__ __attribute__((aligned(16))) uint16_t Xp[HB][3][16 * MT][32];
+template <typename KVT, int MT, int NT, int EPI, int HB, int WL = 0, int LATE = 0>
+__global__ __launch_bounds__(256, LATE ? 4 : 2) void gemm_bx3u_kernel(GemmArgs a) {
+  // DYNAMIC LDS (HB x 3 x 16 MT x 32 bf16 = 48 KB at HB = 8, MT = 2), not a static array: with a static 48 KB the compiler knows
+  // that only three workgroups fit on a CU and pads the kernel's register allocation up to that occupancy (136 VGPRs allocated for
+  // 88-100 used) — registers another stream's workgroups could have had beside it.
+  extern __shared__ __attribute__((aligned(16))) uint16_t Xp[];  // [HB][3][16 MT][32]
+  constexpr int XP_BLK = 3 * 16 * MT * 32, XP_PLANE = 16 * MT * 32;
   launch_stamp_begin(a.ts);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef DSM_WK_STAMPS
@@ -231,21 +235,25 @@ __global__ __launch_bounds__(256, 2) void gemm_bx3u_kernel(GemmArgs a) {
     m = m < a.M ? m : a.M - 1;
     xv[i] = *reinterpret_cast<const float4*>(a.X + a.xmap.off(m) + xoff);
   }
+  // LATE > 0 (r04, late): the last LATE blocks' weight fragments are requested only after the activations have been split and
+  // staged — their registers are the ones the activation pieces held, so the kernel fits 128 VGPRs (four waves per SIMD: two of
+  // its workgroups fit on a CU beside two attention workgroups of the other stream group instead of one)
+  static_assert(LATE == 0 || HB == 8, "the late half is requested between the staging and its barrier");
   uint4 wv[8][NT];
-#pragma unroll
-  for (int g = 0; g < 8; ++g) {
-    const int kb = 32 * (kb0 + (g < nkb ? g : nkb - 1));
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int gc = g < nkb ? g : nkb - 1;
-      if (WL == 0)
-        wv[g][nt] = *reinterpret_cast<const uint4*>(dsm_wbase<uint16_t>(a, W, n_base + nt * a.nt_stride, r, q) + (long)kb * dsm_wstep<uint16_t>(a));
-      else if (WL == 1)
-        wv[g][nt] = *reinterpret_cast<const uint4*>(W + ((long)((n_base + nt * a.nt_stride) >> 4) * (a.Kpad >> 5) + kb0 + gc) * 512 + lane * 8);
-      else
-        wv[g][nt] = *reinterpret_cast<const uint4*>(W + (((long)blockIdx.y * a.w_ntiles * 8) + (long)((n_base + nt * a.nt_stride) >> 4) * nkb + gc) * 512 + lane * 8);
-    }
+#define DSM_WLOAD(G0, G1)                                                                                                              \
+  _Pragma("unroll") for (int g = (G0); g < (G1); ++g) {                                                                               \
+    const int kb = 32 * (kb0 + (g < nkb ? g : nkb - 1));                                                                               \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                                                                \
+      const int gc = g < nkb ? g : nkb - 1;                                                                                            \
+      if (WL == 0)                                                                                                                     \
+        wv[g][nt] = *reinterpret_cast<const uint4*>(dsm_wbase<uint16_t>(a, W, n_base + nt * a.nt_stride, r, q) + (long)kb * dsm_wstep<uint16_t>(a)); \
+      else if (WL == 1)                                                                                                                \
+        wv[g][nt] = *reinterpret_cast<const uint4*>(W + ((long)((n_base + nt * a.nt_stride) >> 4) * (a.Kpad >> 5) + kb0 + gc) * 512 + lane * 8); \
+      else                                                                                                                             \
+        wv[g][nt] = *reinterpret_cast<const uint4*>(W + (((long)blockIdx.y * a.w_ntiles * 8) + (long)((n_base + nt * a.nt_stride) >> 4) * nkb + gc) * 512 + lane * 8); \
+    }                                                                                                                                  \
   }
+  DSM_WLOAD(0, 8 - LATE)
   __builtin_amdgcn_sched_barrier(0);
 #ifdef DSM_WK_STAMPS  // experiments/gemm_wk_probe.hip: per-workgroup phase stamps (wall clock, 10 ns)
 #define DSM_STAMP(i) if (stamp && tid == 0) stamp[i] = wall_clock64();
@@ -271,11 +279,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bx3u_kernel(GemmArgs a) {
         dsm_split3(xv[i].x, &h[0], &m[0], &l[0]); dsm_split3(xv[i].y, &h[1], &m[1], &l[1]);
         dsm_split3(xv[i].z, &h[2], &m[2], &l[2]); dsm_split3(xv[i].w, &h[3], &m[3], &l[3]);
         const int off = row * 32 + (((part >> 1) ^ ((row >> 1) & 3)) * 8) + (part & 1) * 4;
-        uint16_t* base = &Xp[xblk - ph * HB][0][0][0];
+        uint16_t* base = Xp + (xblk - ph * HB) * XP_BLK;
         *reinterpret_cast<uint2*>(base + off) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
         *reinterpret_cast<uint2*>(base + 16 * MT * 32 + off) = make_uint2((uint32_t)m[0] | ((uint32_t)m[1] << 16), (uint32_t)m[2] | ((uint32_t)m[3] << 16));
         *reinterpret_cast<uint2*>(base + 2 * 16 * MT * 32 + off) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
       }
+    }
+    if (LATE > 0) {
+      __builtin_amdgcn_sched_barrier(0);  // the staging stores above, then the late requests: not the other way round
+      DSM_WLOAD(8 - LATE, 8)
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
     if (ph == 0) { DSM_STAMP(1) }
@@ -296,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bx3u_kernel(GemmArgs a) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
             const int row = 16 * mt + r;
-            const dsm_bf16x8 xf = *reinterpret_cast<const dsm_bf16x8*>(&Xp[gg][p][0][0] + row * 32 + ((q ^ ((row >> 1) & 3)) * 8));
+            const dsm_bf16x8 xf = *reinterpret_cast<const dsm_bf16x8*>(Xp + gg * XP_BLK + p * XP_PLANE + row * 32 + ((q ^ ((row >> 1) & 3)) * 8));
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[nt], xf, acc[nt][mt], 0, 0, 0);
           }
@@ -340,6 +353,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bx3u_kernel(GemmArgs a) {
   launch_stamp_end(a.ts);
 #undef DSM_STAMP
 #undef DSM_STAMP_WAIT
+#undef DSM_WLOAD
 }
 
 // ---- gemm_wk_kernel with the row norm of its input in the prologue (r04) -----------------------------------------------------

@@ -1981,14 +1981,20 @@ struct SeanetFrontArgs {
   int T, S0, Sd;
 };
 
+template <int TM>
+constexpr size_t seanet_front_lds() { return sizeof(float) * ((TM + 2) * 64 + TM * 64 + TM * 32 + (TM + 2 + 7 - 1)); }
 template <int TM>  // frames per workgroup: 64 or 32 (smaller tiles: more workgroups per CU to hide the three phases behind each other)
 __global__ __launch_bounds__(256) void seanet_front_kernel(SeanetFrontArgs a) {
   constexpr int C0 = 64, C1 = 32, TAPS0 = 7, MTILES = TM / 16;
   static_assert(TM == 64 || TM == 32, "tile");
-  __shared__ float xs[TM + 2 + TAPS0 - 1];
-  __shared__ __attribute__((aligned(16))) float e0[(TM + 2) * C0];  // ELU(init conv), frames t0-2 .. t0+TM-1; 16-byte unit u of row R at u ^ (R & 15)
-  __shared__ __attribute__((aligned(16))) float y0[TM * C0];        // raw init conv (the skip), same swizzle
-  __shared__ __attribute__((aligned(16))) float hs[TM * C1];        // ELU(conv k 3 + bias): the k-1 conv's activation block (dsm_xs_sw swizzle)
+  // Dynamic LDS (seanet_front_lds<TM>() bytes), not static arrays: a static 41 KB tells the compiler that three workgroups fit on a
+  // CU and it pads the register allocation up to that occupancy (136 VGPRs for 88 used) — registers the LM streams' workgroups
+  // can use beside this kernel (r04, see gemm_bx3u_kernel).
+  extern __shared__ __attribute__((aligned(16))) float front_lds[];
+  float* e0 = front_lds;                    // [(TM + 2) * C0] ELU(init conv), frames t0-2 .. t0+TM-1; 16-byte unit u of row R at u ^ (R & 15)
+  float* y0 = e0 + (TM + 2) * C0;           // [TM * C0] raw init conv (the skip), same swizzle
+  float* hs = y0 + TM * C0;                 // [TM * C1] ELU(conv k 3 + bias): the k-1 conv's activation block (dsm_xs_sw swizzle)
+  float* xs = hs + TM * C1;                 // [TM + 2 + TAPS0 - 1]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int b = blockIdx.y, t0 = blockIdx.x * TM;

@@ -54,19 +54,19 @@ static void launch_old(const Shape& sh, const Bufs& b, int M, int buf, hipStream
   a.ws = b.ws;
   dim3 grid(gx, chunks, (M + 16 * MT - 1) / (16 * MT));
   if (bx3 && form == 1) {
-    if (MT == 4) hipLaunchKernelGGL((gemm_bx3u_kernel<float, 4, NT, EPI, 4>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((gemm_bx3u_kernel<float, 2, NT, EPI, 8>), grid, dim3(256), 0, st, a);
+    if (MT == 4) hipLaunchKernelGGL((gemm_bx3u_kernel<float, 4, NT, EPI, 4>), grid, dim3(256), 4 * 3 * 16 * 4 * 32 * 2, st, a);
+    else hipLaunchKernelGGL((gemm_bx3u_kernel<float, 2, NT, EPI, 8>), grid, dim3(256), 8 * 3 * 16 * 2 * 32 * 2, st, a);
   } else if (bx3 && (form == 3 || form == 4)) {
     a.W = form == 3 ? b.Wt[buf] : b.Wc[buf];
     a.w_ntiles = (sh.N * (EPI == EPI_GATE ? 2 : 1)) / 16;
-    if (MT == 4) { if (form == 3) hipLaunchKernelGGL((gemm_bx3u_kernel<float, 4, NT, EPI, 4, 1>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((gemm_bx3u_kernel<float, 4, NT, EPI, 4, 2>), grid, dim3(256), 0, st, a); }
-    else { if (form == 3) hipLaunchKernelGGL((gemm_bx3u_kernel<float, 2, NT, EPI, 8, 1>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((gemm_bx3u_kernel<float, 2, NT, EPI, 8, 2>), grid, dim3(256), 0, st, a); }
+    if (MT == 4) { if (form == 3) hipLaunchKernelGGL((gemm_bx3u_kernel<float, 4, NT, EPI, 4, 1>), grid, dim3(256), 4 * 3 * 16 * 4 * 32 * 2, st, a); else hipLaunchKernelGGL((gemm_bx3u_kernel<float, 4, NT, EPI, 4, 2>), grid, dim3(256), 4 * 3 * 16 * 4 * 32 * 2, st, a); }
+    else { if (form == 3) hipLaunchKernelGGL((gemm_bx3u_kernel<float, 2, NT, EPI, 8, 1>), grid, dim3(256), 8 * 3 * 16 * 2 * 32 * 2, st, a); else hipLaunchKernelGGL((gemm_bx3u_kernel<float, 2, NT, EPI, 8, 2>), grid, dim3(256), 8 * 3 * 16 * 2 * 32 * 2, st, a); }
   } else if (bx3 && form == 5) {  // M = 64 as two 32-row z-tiles of the MT = 2 kernel (weights read twice: the second time from L2 / MALL)
     dim3 g2(gx, chunks, (M + 31) / 32);
-    hipLaunchKernelGGL((gemm_bx3u_kernel<float, 2, NT, EPI, 8>), g2, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((gemm_bx3u_kernel<float, 2, NT, EPI, 8>), g2, dim3(256), 8 * 3 * 16 * 2 * 32 * 2, st, a);
   } else if (bx3 && form == 2) {
-    if (MT == 4) hipLaunchKernelGGL((gemm_bx3u_kernel<float, 4, NT, EPI, 4>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((gemm_bx3u_kernel<float, 2, NT, EPI, 4>), grid, dim3(256), 0, st, a);
+    if (MT == 4) hipLaunchKernelGGL((gemm_bx3u_kernel<float, 4, NT, EPI, 4>), grid, dim3(256), 4 * 3 * 16 * 4 * 32 * 2, st, a);
+    else hipLaunchKernelGGL((gemm_bx3u_kernel<float, 2, NT, EPI, 4>), grid, dim3(256), 4 * 3 * 16 * 2 * 32 * 2, st, a);
   } else if (bx3) {
     if (MT == 4) hipLaunchKernelGGL((gemm_bx3_kernel<float, 4, NT, EPI, false>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((gemm_bx3_kernel<float, 2, NT, EPI, false>), grid, dim3(256), 0, st, a);
@@ -237,7 +237,7 @@ static void stamps(const Shape& sh, int M, hipStream_t st) {
       a.res = nullptr; a.norm_out = nullptr;
       a.ws_ntiles = (((NT - 1) * a.nt_stride) >> 4) + gx * 4; a.ws = b.ws;
       if (i == 7) { CK(hipMemsetAsync(ts, 0xFF, 16, st)); CK(hipMemsetAsync(ts + 1, 0, 8, st)); a.ts = ts; }
-      hipLaunchKernelGGL((gemm_bx3u_kernel<float, 2, NT, EPI, 8>), dim3(gx, chunks, 1), dim3(256), 0, st, a);
+      hipLaunchKernelGGL((gemm_bx3u_kernel<float, 2, NT, EPI, 8>), dim3(gx, chunks, 1), dim3(256), 8 * 3 * 16 * 2 * 32 * 2, st, a);
     }
     CK(hipStreamSynchronize(st));
   }
