@@ -560,7 +560,7 @@ def main():
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", rnd, "pmc_hbm_traffic.json")))
                 for k in pmc["kernels"]:
-                    if ("attn_kernel<unsigned short, %d, 1>" % hd in k["kernel"] and args.config == "stt-1b-en_fr"
+                    if ("attn_kernel<unsigned short, %d, 1" % hd in k["kernel"] and args.config == "stt-1b-en_fr"
                             and B == 64 and k.get("slots_per_dispatch", 64) * len(groups) == B):
                         traffic = (2 * k["FETCH_SIZE_KB_per_dispatch"] + k["WRITE_SIZE_KB_per_dispatch"]) * 1024
                         traffic_src = f"profiles/{rnd}/pmc_hbm_traffic.json (rocprofv3 --pmc, separate passes; not measured in this run)"

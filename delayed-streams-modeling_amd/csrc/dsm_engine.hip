@@ -234,6 +234,7 @@ struct dsm_engine {
   int wk_gate_max_chunks = 4; // DSM_WK_GATE_CHUNKS: gated-MLP input GEMMs with at most this many K-chunks run whole-K-in-the-workgroup
   bool bx3u_m64 = true;  // DSM_BX3U_M64=0: 33..64-row narrow GEMMs stay on one 64-row tile
   bool bx3u_late = true;  // DSM_BX3U_LATE=0: the 32-row gemm_bx3u_kernel requests all eight weight blocks up front (129-140 VGPRs)
+  int attn_unr = 0;  // DSM_ATTN_UNR=4 / 8: force the bf16-ring attention kernel's keys per lane group and batch (0: by shape)
   bool attn_small = true;  // DSM_ATTN_SMALL=0: rings of at most 32 positions use attn_kernel too
                               // (gemm_wk_kernel: no slabs, no reduce launch); 0: never
   int prio_hi = 0;

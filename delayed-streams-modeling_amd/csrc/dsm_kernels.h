@@ -1124,7 +1124,11 @@ struct AttnFused {
   int q_only;  // the slabs hold a [M][d] query projection only (cross-attention, r04): no K / V rows, no RoPE, nothing scattered
 };
 
-template <typename KVT, int HD, int T>
+// UNRB: keys per lane group and batch on a bf16 ring (8: 126 VGPRs, 4: 78).  The key -> (wave, lane group) assignment and the order
+// inside a group do not depend on it (same bits); 4 leaves registers for the other stream group's GEMM workgroups beside a 32-slot
+// launch and is faster outright at head_dim 64 (stt-2.6b: 39.2 against 42.8 us per 64-slot launch, 9.18 against 9.63 ms per step);
+// 8 keeps the large launches of head_dim 128 at 0.88 of the HBM peak (r04, late; profiles/r04/experiments/timing_notes.txt).
+template <typename KVT, int HD, int T, int UNRB = 8>
 __global__ __launch_bounds__(256, 4) void attn_kernel(float* __restrict__ out, const float* __restrict__ qbuf,
                                                    const KVT* __restrict__ kcache, const KVT* __restrict__ vcache,
                                                    const uint32_t* __restrict__ start_pos,
@@ -1202,7 +1206,7 @@ __global__ __launch_bounds__(256, 4) void attn_kernel(float* __restrict__ out, c
   // 16-byte loads are already in flight (raw cache words, converted at use), so a wave keeps UNR..2*UNR loads
   // outstanding instead of draining to zero every iteration.  Out-of-range keys are clamped to the last valid row
   // (loaded, never used) so that the loads need no branches. ----
-  constexpr int UNR = sizeof(KVT) == 2 ? 8 : 4;
+  constexpr int UNR = sizeof(KVT) == 2 ? UNRB : 4;
   constexpr int STEP = UNR * NW * G;
   const int jlast = nvalid - 1;
   const int last_slot = (int)(e1 % ctx);  // ring slot holding the newest key

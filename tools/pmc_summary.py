@@ -27,7 +27,7 @@ for key, (n, tot) in sorted(fetch.items(), key=lambda kv: -kv[1][1])[:24]:
     name, grid, wg = key
     e = {"kernel": f"{name} grid={grid} wg={wg}", "dispatches": n, "FETCH_SIZE_KB_per_dispatch": round(tot / n, 1),
          "WRITE_SIZE_KB_per_dispatch": round(write[key][1] / max(write[key][0], 1), 1) if key in write else None}
-    if name.startswith("void attn_kernel<unsigned short, 128, 1>"):  # the LM attention
+    if name.startswith("void attn_kernel<unsigned short, 128, 1"):  # the LM attention (a fourth template argument since r04: keys per batch)
         e["slots_per_dispatch"] = grid // wg // heads  # one workgroup per (slot, head)
     out["kernels"].append(e)
 json.dump(out, sys.stdout, indent=1)
