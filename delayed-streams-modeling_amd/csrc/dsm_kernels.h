@@ -1125,9 +1125,9 @@ struct AttnFused {
 };
 
 // UNRB: keys per lane group and batch on a bf16 ring (8: 126 VGPRs, 4: 78).  The key -> (wave, lane group) assignment and the order
-// inside a group do not depend on it (same bits); 4 leaves registers for the other stream group's GEMM workgroups beside a 32-slot
-// launch and is faster outright at head_dim 64 (stt-2.6b: 39.2 against 42.8 us per 64-slot launch, 9.18 against 9.63 ms per step);
-// 8 keeps the large launches of head_dim 128 at 0.88 of the HBM peak (r04, late; profiles/r04/experiments/timing_notes.txt).
+// inside a group do not depend on it (same bits).  4 is faster outright at head_dim 64 (stt-2.6b: 39.2 against 42.8 us per 64-slot
+// launch, 9.18 against 9.63 ms per step); at head_dim 128 the kernel itself is 3-4 % faster with 8 (launch_attn_t picks; r04, late;
+// profiles/r04/experiments/timing_notes.txt).
 template <typename KVT, int HD, int T, int UNRB = 8>
 __global__ __launch_bounds__(256, 4) void attn_kernel(float* __restrict__ out, const float* __restrict__ qbuf,
                                                    const KVT* __restrict__ kcache, const KVT* __restrict__ vcache,
